@@ -1,0 +1,141 @@
+/*
+ * zns.h -- C ABI of libzns_hip.so: the MI355X (gfx950) implementation of the
+ * zeroNoteSamba self-supervised pretext hot path.
+ *
+ * The reference (deezer/zeroNoteSamba) is pure Python: its "FFI" for this path is
+ * the call signature of generate_XQT() and the torch.nn.Module / autograd protocol
+ * of _CNN / DS_CNN / Pretext_CNN / Down_CNN / NTXent.  Each
+ * entry point below names the reference lines it replaces.  INTEGRATION.md shows
+ * the ctypes binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter says "host";
+ *     `const float* const* w` is a HOST array of device pointers (one per branch)
+ *   - tensors are contiguous fp32, NCHW, exactly as the reference modules hold them
+ *   - `nbr` = number of independent-weight branches processed by one launch
+ *     (2 for Pretext_CNN: anchor + postve, 1 for a lone DS_CNN); activations are
+ *     stacked branch-major: [nbr*B, C, H, T]
+ *   - `stream` is a hipStream_t (NULL = default stream); all work is enqueued, no
+ *     host synchronisation, no allocation: the caller owns outputs and workspace
+ *   - return value: 0 on success, otherwise a negative zns error or a positive
+ *     hipError_t; zns_last_error() gives the message (thread local)
+ */
+#ifndef ZNS_H
+#define ZNS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZNS_OK 0
+#define ZNS_ERR_ARG (-1)         /* bad argument / unsupported shape */
+#define ZNS_ERR_WORKSPACE (-2)   /* workspace too small */
+#define ZNS_ERR_MODE (-3)        /* generate_XQT: "Mode can only be vqt or cqt!" (input_rep.py:56-57) */
+
+#define ZNS_IMPL_AUTO 0          /* MFMA / tuned kernels */
+#define ZNS_IMPL_NAIVE 1         /* one-thread-per-output HIP kernels, for on-device validation only */
+
+#define ZNS_REDUCE_MAX 0         /* Down_CNN(reduction="max"), models.py:147-148 */
+#define ZNS_REDUCE_MEAN 1        /* Down_CNN(reduction="mean"), models.py:144-145 */
+
+#define ZNS_MODE_VQT 0           /* input_rep.py:41-54 */
+#define ZNS_MODE_CQT 1           /* input_rep.py:26-39 */
+
+const char* zns_last_error(void);
+int zns_version(void);
+/* Select the kernel family for conv fwd/dgrad/wgrad (process global).  Returns the previous value. */
+int zns_set_impl(int impl);
+
+/* ------------------------------------------------------------------ conv layers
+ * One call = one `nn.Conv2d` (+ the MaxPool2d/ReLU/Dropout that follow it) of
+ * _CNN.forward, models.py:37-70, for `nbr` branches at once.
+ *   y = dropout(relu(maxpool_{(pool,1)}(conv2d(x, w, b, padding=(kh/2, kw/2)))))
+ * argmax (may be NULL when pool==1 or for inference) receives, per output element,
+ * the row offset 0..pool-1 of the pooled maximum (first maximum wins, as ATen).
+ * drop_p == 0 disables dropout (module.eval()).  The keep mask is a stateless hash
+ * of (seed, layer, branch, linear index of y within its branch); see csrc/zns_common.h.
+ */
+size_t zns_conv2d_workspace_bytes(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H);
+
+int zns_conv2d_fwd_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, int pool,
+                       const float* x, const float* const* w, const float* const* bias,
+                       float* y, uint8_t* argmax,
+                       float drop_p, uint32_t seed, int layer,
+                       void* ws, size_t ws_bytes, void* stream);
+
+/* Backward-data of the same conv (autograd of models.py:37-70):
+ *   dx_raw = conv_transpose(dz, w)                      [nbr*B, cin, H, T]
+ * fused epilogue (all optional):
+ *   g  = dx_raw * (x != 0) * inv_keep    -- ReLU+Dropout backward of the PREVIOUS layer
+ *                                           (x is this conv's input = previous layer's output)
+ *   if prev_pool > 1: dx[.., h*prev_pool + a, ..] = (a == prev_argmax) ? g : 0   -- MaxPool backward,
+ *        dx is then [nbr*B, cin, H*prev_pool, T] = grad w.r.t. the previous conv's raw output
+ *   else dx = g
+ * dz is the gradient w.r.t. this conv's RAW output [nbr*B, cout, H, T].
+ */
+int zns_conv2d_dgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H,
+                         const float* dz, const float* const* w, float* dx,
+                         const float* x, float inv_keep, const uint8_t* prev_argmax, int prev_pool,
+                         void* ws, size_t ws_bytes, void* stream);
+
+/* Backward-weights: dw[br] (+)= sum_{b,h,t} dz (x) shifted x ; db[br] (+)= sum dz.
+ * accumulate != 0 adds into dw/db (gradient accumulation), else overwrites. */
+int zns_conv2d_wgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H,
+                         const float* dz, const float* x, float* const* dw, float* const* db,
+                         int accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ DS_CNN head
+ * emb[n, t] = sigmoid(sum_c w[c] * h[n, c, t] + b)   (fc1 + sig + reshape, models.py:99-101) */
+int zns_head_fwd_f32(int nbr, int B, int T, int C, const float* h, const float* const* w,
+                     const float* const* b, float* emb, void* stream);
+/* Given demb: dz8 = demb*emb*(1-emb) * w[c] * (h != 0) * inv_keep  (grad w.r.t. cv8 raw output),
+ * dw[c] (+)= sum demb*emb*(1-emb)*h, db (+)= sum demb*emb*(1-emb). */
+int zns_head_bwd_f32(int nbr, int B, int T, int C, const float* h, const float* emb, const float* demb,
+                     const float* const* w, float inv_keep, float* dz, float* const* dw, float* const* db,
+                     int accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ Down_CNN combine (models.py:144-148) */
+int zns_down_fwd_f32(const float* a, const float* p, size_t n, int reduction, float* out, void* stream);
+int zns_down_bwd_f32(const float* a, const float* p, const float* dout, size_t n, int reduction,
+                     float* da, float* dp, void* stream);
+
+/* ------------------------------------------------------------------ NT-Xent (loss_functions.py:24-55)
+ * a, p: [rows, D] (rows <= batch_len).  out3 (device, 3 floats): loss, mean anchor/positive
+ * cosine, mean anchor/negative cosine -- all divided by batch_len as the reference does.
+ * ga/gp (nullable): d(loss*grad_scale)/da, /dp. */
+int zns_ntxent_f32(const float* a, const float* p, int rows, int D, int batch_len, float tau,
+                   float* out3, float* ga, float* gp, float grad_scale, void* stream);
+
+/* BCELoss(mean) forward + backward (loader.py:16, epochs.py:61): loss (device scalar), dout nullable */
+int zns_bce_f32(const float* out, const float* target, size_t n, float* loss, float* dout,
+                float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------ Adam (pretext.py:202, loader.py:43)
+ * torch.optim.Adam semantics: no weight decay, no amsgrad.  `step` is 1-based.
+ * g is multiplied by grad_scale first (1/world_size after an all-reduce(sum)). */
+int zns_adam_step_f32(float* p, const float* g, float* m, float* v, size_t n,
+                      float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                      void* stream);
+
+/* ------------------------------------------------------------------ generate_XQT (input_rep.py:11-57)
+ * wav: [n_clips, n_samples] fp32 @16 kHz; out: [n_clips, 96, 1 + n_samples/256] = log(|XQT| + 1e-9).
+ * mode: ZNS_MODE_VQT / ZNS_MODE_CQT, anything else -> ZNS_ERR_MODE.
+ * The filter bank (host, float64) is built once per (mode) and cached on the device. */
+size_t zns_xqt_workspace_bytes(int n_clips, int n_samples, int mode);
+int zns_xqt_frames(int n_samples);
+int zns_xqt_f32(const float* wav, int n_clips, int n_samples, int sample_rate, int mode,
+                float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ shift batching (pretext.py:285-292,308-321)
+ * bank: [n_bank, 2, 96, bank_T]; for item i of the batch: out[i] = bank[clip[i], :, :, start[i]:start[i]+T]
+ * out is laid out branch-major for the twin launch: [2, n_items, 96, T]. clip/start are device int32. */
+int zns_shift_gather_f32(const float* bank, int bank_T, const int32_t* clip, const int32_t* start,
+                         int n_items, int T, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZNS_H */

@@ -1,0 +1,202 @@
+"""GPU parity, layer by layer, through the C ABI: every conv layer's forward / backward-data /
+backward-weights (naive AND MFMA kernel families) against stock torch CPU ops (the oracle's building
+blocks) on the same seeded inputs.  Tolerance: 1e-4 relative to the tensor's max magnitude (fp32,
+K up to 26 880)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dropout_ref  # noqa: E402
+
+
+def _mods():
+    from zeronotesamba_amd import _lib, _ops
+    return _lib, _ops
+
+
+def rnd(seed, shape, scale=1.0):
+    n = int(np.prod(shape))
+    return torch.from_numpy((dropout_ref.uniform_pm1(seed, n) * np.float32(scale)).astype(np.float32).reshape(shape).copy())
+
+
+def close(got: torch.Tensor, ref: torch.Tensor, tol=1e-4, what=""):
+    got = got.detach().cpu().double()
+    ref = ref.detach().double()
+    scale = max(ref.abs().max().item(), 1e-30)
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+CASES = [(li, impl) for li in range(8) for impl in ("naive", "mfma")]
+
+
+@pytest.mark.parametrize("li,impl", CASES)
+@pytest.mark.parametrize("T", [40, 64])
+def test_conv_layer(li, impl, T):
+    _lib, _ops = _mods()
+    L = _lib.lib()
+    name, cin, cout, kh, kw, pool = _ops.LAYERS[li]
+    H = _ops.H_IN[li]
+    nbr, B = 2, 2
+    dev = torch.device("cuda:0")
+    x = rnd(10 + li, (nbr * B, cin, H, T))
+    # post-ReLU/dropout-like input with exact zeros, so the fused mask in dgrad is exercised
+    x = torch.where(x > -0.3, x, torch.zeros_like(x))
+    w = [rnd(20 + li + 100 * br, (cout, cin, kh, kw), 1.0 / np.sqrt(cin * kh * kw)) for br in range(nbr)]
+    b = [rnd(30 + li + 100 * br, (cout,), 0.1) for br in range(nbr)]
+
+    # ---- oracle building blocks on CPU
+    ws_cpu = [t.clone().requires_grad_(True) for t in w]
+    bs_cpu = [t.clone().requires_grad_(True) for t in b]
+    zs, ys, ams = [], [], []
+    for br in range(nbr):
+        z = F.conv2d(x[br * B:(br + 1) * B], ws_cpu[br], bs_cpu[br], padding=(kh // 2, kw // 2))
+        zs.append(z)
+        if pool > 1:
+            yp, am = F.max_pool2d(z, (pool, 1), return_indices=True)
+        else:
+            yp, am = z, None
+        ys.append(F.relu(yp))
+        ams.append(am)
+    y_ref = torch.cat(ys).detach()
+
+    prev = L.zns_set_impl(_lib.ZNS_IMPL_NAIVE if impl == "naive" else _lib.ZNS_IMPL_AUTO)
+    try:
+        xd = x.to(dev)
+        wd = [t.to(dev) for t in w]
+        bd = [t.to(dev) for t in b]
+        ws = _ops.workspace(_ops.conv_workspace_bytes(nbr, B, T), dev)
+        # ---------------- forward (eval)
+        y, am = _ops.conv_fwd(li, nbr, B, T, xd, wd, bd, 0.0, 0, True, ws)
+        torch.cuda.synchronize()
+        close(y, y_ref, what=f"{name} fwd")
+        if pool > 1:
+            # argmax: compare the selected VALUE (ties may pick another row)
+            zcat = torch.cat(zs).detach()
+            hp = H // pool
+            zc = zcat.reshape(nbr * B, cout, hp, pool, T)
+            sel = torch.gather(zc, 3, am.cpu().long().unsqueeze(3)).squeeze(3)
+            close(sel, zc.max(dim=3).values, what=f"{name} argmax value")
+            assert int(am.max()) < pool
+        # ---------------- forward (train): same mask as the numpy restatement of the hash
+        seed = 4242
+        yt, _ = _ops.conv_fwd(li, nbr, B, T, xd, wd, bd, 0.1, seed, True, ws)
+        keep = []
+        for br in range(nbr):
+            keep.append(dropout_ref.keep_mask(dropout_ref.layer_seed(seed, li, br), tuple(ys[br].shape), 0.1))
+        keep = torch.from_numpy(np.concatenate(keep).astype(np.float32))
+        close(yt, y_ref * keep * np.float32(1.0 / 0.9), what=f"{name} fwd train-mode")
+        # ---------------- backward-weights
+        dz = rnd(40 + li, tuple(torch.cat(zs).shape))
+        loss = sum((zs[br] * dz[br * B:(br + 1) * B]).sum() for br in range(nbr))
+        loss.backward()
+        dzd = dz.to(dev)
+        dw = [torch.full_like(t, 7.0) for t in wd]
+        db = [torch.full_like(t, 7.0) for t in bd]
+        _ops.conv_wgrad(li, nbr, B, T, dzd, xd, dw, db, False, ws)
+        for br in range(nbr):
+            close(dw[br], ws_cpu[br].grad, what=f"{name} wgrad br{br}")
+            close(db[br], bs_cpu[br].grad, what=f"{name} bgrad br{br}")
+        # accumulate=True adds on top
+        _ops.conv_wgrad(li, nbr, B, T, dzd, xd, dw, db, True, ws)
+        close(dw[0], 2 * ws_cpu[0].grad, what=f"{name} wgrad accumulate")
+        # ---------------- backward-data with fused ReLU/dropout mask + unpool of the previous layer
+        if li > 0:
+            prev_pool = _ops.LAYERS[li - 1][5]
+            xg = x.clone().requires_grad_(True)
+            dx_refs = []
+            for br in range(nbr):
+                zz = F.conv2d(xg[br * B:(br + 1) * B], w[br], None, padding=(kh // 2, kw // 2))
+                (zz * dz[br * B:(br + 1) * B]).sum().backward()
+            inv_keep = 1.0 / 0.9
+            g_ref = xg.grad * (x != 0).float() * inv_keep
+            pam = None
+            if prev_pool > 1:
+                pam_cpu = torch.from_numpy(
+                    (dropout_ref.hash_u32(77, np.arange(x.numel(), dtype=np.uint64)) % prev_pool)
+                    .astype(np.uint8).reshape(tuple(x.shape)))
+                pam = pam_cpu.to(dev)
+                full = torch.zeros(nbr * B, cin, H, prev_pool, T)
+                full.scatter_(3, pam_cpu.long().unsqueeze(3), g_ref.unsqueeze(3))
+                g_ref = full.reshape(nbr * B, cin, H * prev_pool, T)
+            dx = _ops.conv_dgrad(li, nbr, B, T, dzd, wd, xd, inv_keep, pam, prev_pool, ws)
+            close(dx, g_ref, what=f"{name} dgrad")
+            # no-mask variant
+            dx2 = _ops.conv_dgrad(li, nbr, B, T, dzd, wd, None, 1.0, None, 1, ws)
+            close(dx2, xg.grad, what=f"{name} dgrad (no epilogue)")
+        torch.cuda.synchronize()
+    finally:
+        L.zns_set_impl(prev)
+
+
+def test_head_and_down():
+    _lib, _ops = _mods()
+    dev = torch.device("cuda:0")
+    nbr, B, T = 2, 3, 50
+    h = rnd(1, (nbr * B, 128, 1, T))
+    h = torch.where(h > 0, h, torch.zeros_like(h))
+    w = [rnd(2 + br, (1, 128, 1), 0.3) for br in range(nbr)]
+    b = [rnd(4 + br, (1,), 0.3) for br in range(nbr)]
+    hc = h.clone().requires_grad_(True)
+    wc = [t.clone().requires_grad_(True) for t in w]
+    bc = [t.clone().requires_grad_(True) for t in b]
+    embs = [torch.sigmoid(F.conv1d(hc[br * B:(br + 1) * B].squeeze(2), wc[br], bc[br])).reshape(B, T)
+            for br in range(nbr)]
+    emb_ref = torch.cat(embs)
+    demb = rnd(9, (nbr * B, T))
+    (emb_ref * demb).sum().backward()
+    hd = h.to(dev)
+    wd = [t.to(dev) for t in w]
+    bd = [t.to(dev) for t in b]
+    emb = _ops.head_fwd(nbr, B, T, hd, wd, bd)
+    close(emb, emb_ref, tol=2e-6, what="head fwd")
+    dw = [torch.zeros_like(t) for t in wd]
+    db = [torch.zeros_like(t) for t in bd]
+    ws = _ops.workspace(1 << 20, dev)
+    dz = _ops.head_bwd(nbr, B, T, hd, emb, demb.to(dev), wd, 1.0 / 0.9, dw, db, False, ws)
+    close(dz, hc.grad * (h != 0).float() / 0.9, what="head dz")
+    for br in range(nbr):
+        close(dw[br], wc[br].grad, what="head dw")
+        close(db[br], bc[br].grad, what="head db")
+    # Down_CNN combine
+    a = rnd(11, (4, 33)).abs()
+    p = rnd(12, (4, 33)).abs()
+    p[0, :5] = a[0, :5]  # ties
+    for red, code in (("max", _lib.ZNS_REDUCE_MAX), ("mean", _lib.ZNS_REDUCE_MEAN)):
+        ac, pc = a.clone().requires_grad_(True), p.clone().requires_grad_(True)
+        o = torch.maximum(ac, pc) if red == "max" else torch.div(ac + pc, 2)
+        g = rnd(13, (4, 33))
+        (o * g).sum().backward()
+        ad, pd = a.to(dev), p.to(dev)
+        out = torch.empty_like(ad)
+        _lib.check(_lib.lib().zns_down_fwd_f32(ad.data_ptr(), pd.data_ptr(), ad.numel(), code, out.data_ptr(),
+                                               _ops.stream_ptr()), "down_fwd")
+        close(out, o, tol=1e-7, what="down fwd")
+        da, dp = torch.empty_like(ad), torch.empty_like(pd)
+        _lib.check(_lib.lib().zns_down_bwd_f32(ad.data_ptr(), pd.data_ptr(), g.to(dev).data_ptr(), ad.numel(), code,
+                                               da.data_ptr(), dp.data_ptr(), _ops.stream_ptr()), "down_bwd")
+        close(da, ac.grad, tol=1e-7, what="down da")
+        close(dp, pc.grad, tol=1e-7, what="down dp")
+
+
+def test_unsupported_and_bad_arguments_fail_loudly():
+    _lib, _ops = _mods()
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    x = torch.zeros(1, 3, 8, 16, device=dev)
+    w = [torch.zeros(5, 3, 3, 3, device=dev)]
+    b = [torch.zeros(5, device=dev)]
+    y = torch.zeros(1, 5, 8, 16, device=dev)
+    ws = _ops.workspace(1 << 20, dev)
+    rc = L.zns_conv2d_fwd_f32(1, 1, 16, 3, 5, 3, 3, 8, 1, x.data_ptr(), _ops._pp(w), _ops._pp(b), y.data_ptr(), None,
+                              0.0, 0, 0, ws.data_ptr(), ws.numel(), _ops.stream_ptr())
+    assert rc == -1 and b"no gfx950 kernel instance" in L.zns_last_error()
+    rc = L.zns_conv2d_fwd_f32(3, 1, 16, 1, 64, 3, 11, 96, 1, x.data_ptr(), _ops._pp(w), _ops._pp(b), y.data_ptr(),
+                              None, 0.0, 0, 0, ws.data_ptr(), ws.numel(), _ops.stream_ptr())
+    assert rc == -1
+    rc = L.zns_conv2d_fwd_f32(1, 0, 16, 1, 64, 3, 11, 96, 1, x.data_ptr(), _ops._pp(w), _ops._pp(b), y.data_ptr(),
+                              None, 0.0, 0, 0, ws.data_ptr(), ws.numel(), _ops.stream_ptr())
+    assert rc == -1 and b"empty" in L.zns_last_error()

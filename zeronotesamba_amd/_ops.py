@@ -1,0 +1,200 @@
+"""Host glue between torch tensors (device memory + streams only) and the C ABI (include/zns.h).
+
+Nothing here computes: every function checks shapes, allocates outputs with torch's caching
+allocator, and enqueues HIP kernels on torch's current stream through ctypes.
+"""
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+# (name, cin, cout, kh, kw, pool) -- /root/reference/zeroNoteSamba/models/models.py:16-28
+LAYERS: List[Tuple[str, int, int, int, int, int]] = [
+    ("cv1", 1, 64, 3, 11, 1),
+    ("cv2", 64, 64, 7, 13, 3),
+    ("cv3", 64, 128, 5, 15, 1),
+    ("cv4", 128, 128, 9, 17, 4),
+    ("cv5", 128, 256, 3, 19, 1),
+    ("cv6", 256, 256, 5, 21, 8),
+    ("cv7", 256, 128, 1, 23, 1),
+    ("cv8", 128, 128, 1, 25, 1),
+]
+H_IN = [96, 96, 32, 32, 8, 8, 1, 1]   # rows seen by each conv (n_bins = 96, models.py pools 3, 4, 8)
+DROP_P = 0.1                           # models.py:30
+N_BINS = 96
+
+_workspaces: Dict[Tuple[int, int], torch.Tensor] = {}
+
+
+def require_device(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"zeronotesamba_amd: {what} is on '{t.device}'. This package has no CPU path: move the module and "
+            "its inputs to a ROCm device (.to('cuda')).")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"zeronotesamba_amd: {what} must be float32, got {t.dtype}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def workspace(nbytes: int, device: torch.device, slot: int = 0) -> torch.Tensor:
+    """Grow-only scratch buffer per (device, slot).  slot lets two users overlap safely."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), slot)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def conv_workspace_bytes(nbr: int, B: int, T: int) -> int:
+    L = _lib.lib()
+    need = 0
+    for (name, cin, cout, kh, kw, pool), H in zip(LAYERS, H_IN):
+        need = max(need, L.zns_conv2d_workspace_bytes(nbr, B, T, cin, cout, kh, kw, H))
+    return max(need, (nbr * B * 129 + 64) * 4)
+
+
+def _pp(tensors: Sequence[torch.Tensor]):
+    return _lib.ptr_array([t.data_ptr() for t in tensors])
+
+
+def conv_fwd(li: int, nbr: int, B: int, T: int, x: torch.Tensor, w: Sequence[torch.Tensor],
+             b: Sequence[torch.Tensor], drop_p: float, seed: int, want_argmax: bool, ws: torch.Tensor):
+    name, cin, cout, kh, kw, pool = LAYERS[li]
+    H = H_IN[li]
+    y = torch.empty((nbr * B, cout, H // pool, T), dtype=torch.float32, device=x.device)
+    am = None
+    if pool > 1 and want_argmax:
+        am = torch.empty((nbr * B, cout, H // pool, T), dtype=torch.uint8, device=x.device)
+    rc = _lib.lib().zns_conv2d_fwd_f32(nbr, B, T, cin, cout, kh, kw, H, pool, x.data_ptr(), _pp(w), _pp(b),
+                                       y.data_ptr(), am.data_ptr() if am is not None else None,
+                                       float(drop_p), int(seed) & 0xFFFFFFFF, li,
+                                       ws.data_ptr(), ws.numel(), stream_ptr())
+    _lib.check(rc, f"zns_conv2d_fwd_f32[{name}]")
+    return y, am
+
+
+def conv_dgrad(li: int, nbr: int, B: int, T: int, dz: torch.Tensor, w: Sequence[torch.Tensor],
+               x: Optional[torch.Tensor], inv_keep: float, prev_argmax: Optional[torch.Tensor], prev_pool: int,
+               ws: torch.Tensor) -> torch.Tensor:
+    name, cin, cout, kh, kw, pool = LAYERS[li]
+    H = H_IN[li]
+    dx = torch.empty((nbr * B, cin, H * prev_pool, T), dtype=torch.float32, device=dz.device)
+    rc = _lib.lib().zns_conv2d_dgrad_f32(nbr, B, T, cin, cout, kh, kw, H, dz.data_ptr(), _pp(w), dx.data_ptr(),
+                                         x.data_ptr() if x is not None else None, float(inv_keep),
+                                         prev_argmax.data_ptr() if prev_argmax is not None else None, prev_pool,
+                                         ws.data_ptr(), ws.numel(), stream_ptr())
+    _lib.check(rc, f"zns_conv2d_dgrad_f32[{name}]")
+    return dx
+
+
+def conv_wgrad(li: int, nbr: int, B: int, T: int, dz: torch.Tensor, x: torch.Tensor, dw: Sequence[torch.Tensor],
+               db: Sequence[torch.Tensor], accumulate: bool, ws: torch.Tensor) -> None:
+    name, cin, cout, kh, kw, pool = LAYERS[li]
+    H = H_IN[li]
+    rc = _lib.lib().zns_conv2d_wgrad_f32(nbr, B, T, cin, cout, kh, kw, H, dz.data_ptr(), x.data_ptr(), _pp(dw),
+                                         _pp(db), int(bool(accumulate)), ws.data_ptr(), ws.numel(), stream_ptr())
+    _lib.check(rc, f"zns_conv2d_wgrad_f32[{name}]")
+
+
+def head_fwd(nbr: int, B: int, T: int, h: torch.Tensor, w: Sequence[torch.Tensor], b: Sequence[torch.Tensor]):
+    emb = torch.empty((nbr * B, T), dtype=torch.float32, device=h.device)
+    rc = _lib.lib().zns_head_fwd_f32(nbr, B, T, 128, h.data_ptr(), _pp(w), _pp(b), emb.data_ptr(), stream_ptr())
+    _lib.check(rc, "zns_head_fwd_f32")
+    return emb
+
+
+def head_bwd(nbr: int, B: int, T: int, h: torch.Tensor, emb: torch.Tensor, demb: torch.Tensor,
+             w: Sequence[torch.Tensor], inv_keep: float, dw: Sequence[torch.Tensor], db: Sequence[torch.Tensor],
+             accumulate: bool, ws: torch.Tensor) -> torch.Tensor:
+    dz = torch.empty_like(h)
+    rc = _lib.lib().zns_head_bwd_f32(nbr, B, T, 128, h.data_ptr(), emb.data_ptr(), demb.data_ptr(), _pp(w),
+                                     float(inv_keep), dz.data_ptr(), _pp(dw), _pp(db), int(bool(accumulate)),
+                                     ws.data_ptr(), ws.numel(), stream_ptr())
+    _lib.check(rc, "zns_head_bwd_f32")
+    return dz
+
+
+class StackParams:
+    """Per-branch parameter tensors of nbr DS_CNN stacks, in LAYERS order."""
+
+    def __init__(self, conv_w: List[List[torch.Tensor]], conv_b: List[List[torch.Tensor]],
+                 fc_w: List[torch.Tensor], fc_b: List[torch.Tensor]):
+        self.conv_w, self.conv_b, self.fc_w, self.fc_b = conv_w, conv_b, fc_w, fc_b
+        self.nbr = len(fc_w)
+
+    def flat(self) -> List[torch.Tensor]:
+        out: List[torch.Tensor] = []
+        for br in range(self.nbr):
+            for li in range(8):
+                out += [self.conv_w[li][br], self.conv_b[li][br]]
+            out += [self.fc_w[br], self.fc_b[br]]
+        return out
+
+    @staticmethod
+    def from_flat(flat: Sequence[torch.Tensor], nbr: int) -> "StackParams":
+        per = 18
+        cw = [[flat[br * per + 2 * li] for br in range(nbr)] for li in range(8)]
+        cb = [[flat[br * per + 2 * li + 1] for br in range(nbr)] for li in range(8)]
+        fw = [flat[br * per + 16] for br in range(nbr)]
+        fb = [flat[br * per + 17] for br in range(nbr)]
+        return StackParams(cw, cb, fw, fb)
+
+
+def stack_forward(x: torch.Tensor, P: StackParams, B: int, drop_p: float, seed: int, save: bool,
+                  with_head: bool = True):
+    """x: [nbr*B, 1, 96, T] -> (emb [nbr*B, T] or None, acts [y1..y8], argmax {layer: u8})."""
+    nbr = P.nbr
+    T = x.shape[-1]
+    ws = workspace(conv_workspace_bytes(nbr, B, T), x.device)
+    acts: List[torch.Tensor] = []
+    argm: Dict[int, torch.Tensor] = {}
+    cur = x
+    for li in range(8):
+        y, am = conv_fwd(li, nbr, B, T, cur, P.conv_w[li], P.conv_b[li], drop_p, seed, save, ws)
+        if save:
+            acts.append(y)
+            if am is not None:
+                argm[li] = am
+        cur = y
+    emb = head_fwd(nbr, B, T, cur, P.fc_w, P.fc_b) if with_head else None
+    if not save:
+        acts = [cur]
+    return emb, acts, argm
+
+
+def stack_backward(x: torch.Tensor, P: StackParams, B: int, acts: List[torch.Tensor], argm: Dict[int, torch.Tensor],
+                   emb: Optional[torch.Tensor], demb: Optional[torch.Tensor], dh: Optional[torch.Tensor],
+                   inv_keep: float, G: StackParams, accumulate: bool = False, conv_grads: bool = True,
+                   after_layer=None) -> None:
+    """Writes parameter gradients into the tensors of G (same structure as P).
+
+    demb: grad w.r.t. the embeddings (head fused) -- or dh: grad w.r.t. cv8's RAW output when the head
+    was not part of the stack.  after_layer(name) is called after each layer's gradients are enqueued
+    (fc1, cv8, ..., cv1): the hook the data-parallel trainer uses to start bucketed all-reduces.
+    """
+    nbr = P.nbr
+    T = x.shape[-1]
+    ws = workspace(conv_workspace_bytes(nbr, B, T), x.device)
+    if demb is not None:
+        dz = head_bwd(nbr, B, T, acts[7], emb, demb, P.fc_w, inv_keep, G.fc_w, G.fc_b, accumulate, ws)
+        if after_layer:
+            after_layer("fc1")
+    else:
+        dz = dh
+    if not conv_grads:
+        return
+    for li in range(7, 0, -1):
+        xin = acts[li - 1]
+        conv_wgrad(li, nbr, B, T, dz, xin, G.conv_w[li], G.conv_b[li], accumulate, ws)
+        if after_layer:
+            after_layer(LAYERS[li][0])
+        prev_pool = LAYERS[li - 1][5]
+        dz = conv_dgrad(li, nbr, B, T, dz, P.conv_w[li], xin, inv_keep, argm.get(li - 1), prev_pool, ws)
+    conv_wgrad(0, nbr, B, T, dz, x, G.conv_w[0], G.conv_b[0], accumulate, ws)
+    if after_layer:
+        after_layer("cv1")

@@ -1,0 +1,109 @@
+// extern "C" entry points for the conv layers + error plumbing (see include/zns.h).
+#include <stdarg.h>
+#include <string.h>
+
+#include "zns_common.h"
+#include "zns_kernels.h"
+
+namespace zns {
+
+static thread_local char g_err[512] = "";
+static int g_impl = ZNS_IMPL_AUTO;
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+static bool is_cv1(const ConvArgs& a) { return a.cin == 1 && a.cout == 64 && a.kh == 3 && a.kw == 11; }
+
+static int check_conv(const ConvArgs& a, const char* who) {
+    ZNS_CHECK_ARG(a.nbr >= 1 && a.nbr <= 2, "%s: nbr=%d not in {1,2}", who, a.nbr);
+    ZNS_CHECK_ARG(a.B >= 1 && a.T >= 1 && a.H >= 1, "%s: empty batch/time axis (B=%d T=%d H=%d)", who, a.B, a.T, a.H);
+    ZNS_CHECK_ARG(a.cin >= 1 && a.cout >= 1 && (a.kh & 1) && (a.kw & 1), "%s: bad conv geometry", who);
+    ZNS_CHECK_ARG(a.pool >= 1 && a.H % a.pool == 0, "%s: pool=%d does not divide H=%d", who, a.pool, a.H);
+    return ZNS_OK;
+}
+
+}  // namespace zns
+
+using namespace zns;
+
+extern "C" {
+
+const char* zns_last_error(void) { return g_err; }
+int zns_version(void) { return 100; }
+int zns_set_impl(int impl) {
+    const int prev = g_impl;
+    g_impl = impl;
+    return prev;
+}
+
+size_t zns_conv2d_workspace_bytes(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H) {
+    ConvArgs a{nbr, B, T, cin, cout, kh, kw, H, 1};
+    size_t n = 256;
+    if (is_cv1(a)) n = cv1_workspace_bytes(a);
+    else if (mfma_supported(a)) n = mfma_workspace_bytes(a);
+    return (n + 255) & ~(size_t)255;
+}
+
+int zns_conv2d_fwd_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, int pool, const float* x,
+                       const float* const* w, const float* const* bias, float* y, uint8_t* argmax, float drop_p,
+                       uint32_t seed, int layer, void* ws, size_t ws_bytes, void* stream) {
+    ConvArgs a{nbr, B, T, cin, cout, kh, kw, H, pool};
+    int rc = check_conv(a, "conv2d_fwd");
+    if (rc) return rc;
+    ZNS_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "conv2d_fwd: drop_p=%f", drop_p);
+    Ptr2 pw{}, pb{};
+    for (int i = 0; i < nbr; ++i) { pw.p[i] = w[i]; pb.p[i] = bias[i]; }
+    hipStream_t st = (hipStream_t)stream;
+    if (g_impl == ZNS_IMPL_NAIVE) return naive_fwd(a, x, pw, pb, y, argmax, drop_p, seed, layer, st);
+    if (is_cv1(a) && pool == 1) return cv1_fwd(a, x, pw, pb, y, drop_p, seed, layer, st);
+    if (mfma_supported(a)) return mfma_fwd(a, x, pw, pb, y, argmax, drop_p, seed, layer, ws, ws_bytes, st);
+    set_error("conv2d_fwd: no gfx950 kernel instance for cin=%d cout=%d k=%dx%d H=%d", cin, cout, kh, kw, H);
+    return ZNS_ERR_ARG;
+}
+
+int zns_conv2d_dgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, const float* dz,
+                         const float* const* w, float* dx, const float* x, float inv_keep,
+                         const uint8_t* prev_argmax, int prev_pool, void* ws, size_t ws_bytes, void* stream) {
+    ConvArgs a{nbr, B, T, cin, cout, kh, kw, H, 1};
+    int rc = check_conv(a, "conv2d_dgrad");
+    if (rc) return rc;
+    ZNS_CHECK_ARG(prev_pool >= 1 && (prev_pool == 1 || prev_argmax != nullptr), "conv2d_dgrad: prev_pool/argmax");
+    Ptr2 pw{};
+    for (int i = 0; i < nbr; ++i) pw.p[i] = w[i];
+    hipStream_t st = (hipStream_t)stream;
+    if (g_impl == ZNS_IMPL_NAIVE) return naive_dgrad(a, dz, pw, dx, x, inv_keep, prev_argmax, prev_pool, st);
+    if (mfma_supported(a)) return mfma_dgrad(a, dz, pw, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
+    set_error("conv2d_dgrad: no gfx950 kernel instance for cin=%d cout=%d k=%dx%d H=%d", cin, cout, kh, kw, H);
+    return ZNS_ERR_ARG;
+}
+
+int zns_conv2d_wgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, const float* dz,
+                         const float* x, float* const* dw, float* const* db, int accumulate, void* ws,
+                         size_t ws_bytes, void* stream) {
+    ConvArgs a{nbr, B, T, cin, cout, kh, kw, H, 1};
+    int rc = check_conv(a, "conv2d_wgrad");
+    if (rc) return rc;
+    MPtr2 pdw{}, pdb{};
+    for (int i = 0; i < nbr; ++i) { pdw.p[i] = dw[i]; pdb.p[i] = db[i]; }
+    hipStream_t st = (hipStream_t)stream;
+    if (g_impl == ZNS_IMPL_NAIVE) {
+        rc = naive_wgrad(a, dz, x, pdw, accumulate, st);
+        if (rc) return rc;
+        return channel_sum(nbr, B, cout, (long long)H * T, dz, pdb, accumulate, st);
+    }
+    if (is_cv1(a)) return cv1_wgrad(a, dz, x, pdw, pdb, accumulate, ws, ws_bytes, st);
+    if (mfma_supported(a)) {
+        rc = mfma_wgrad(a, dz, x, pdw, accumulate, ws, ws_bytes, st);
+        if (rc) return rc;
+        return channel_sum(nbr, B, cout, (long long)H * T, dz, pdb, accumulate, st);
+    }
+    set_error("conv2d_wgrad: no gfx950 kernel instance for cin=%d cout=%d k=%dx%d H=%d", cin, cout, kh, kw, H);
+    return ZNS_ERR_ARG;
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+// Shared device/host helpers for libzns_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/zns.h"
+
+namespace zns {
+
+void set_error(const char* fmt, ...);
+
+#define ZNS_CHECK_ARG(cond, ...)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            zns::set_error(__VA_ARGS__);         \
+            return ZNS_ERR_ARG;                  \
+        }                                        \
+    } while (0)
+
+#define ZNS_HIP(expr)                                                                  \
+    do {                                                                               \
+        hipError_t e__ = (expr);                                                       \
+        if (e__ != hipSuccess) {                                                       \
+            zns::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return (int)e__;                                                           \
+        }                                                                              \
+    } while (0)
+
+#define ZNS_LAUNCH_CHECK()                                                             \
+    do {                                                                               \
+        hipError_t e__ = hipGetLastError();                                            \
+        if (e__ != hipSuccess) {                                                       \
+            zns::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e__), __FILE__, __LINE__); \
+            return (int)e__;                                                           \
+        }                                                                              \
+    } while (0)
+
+// ---- stateless dropout hash (restated in oracle/dropout_ref.py) ----
+__host__ __device__ inline uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+__host__ __device__ inline uint32_t hash_u32(uint32_t seed, uint64_t idx) {
+    uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+    return lowbias32((lo * 0x9E3779B1u) ^ seed ^ (hi * 0x7FEB352Du));
+}
+__host__ __device__ inline uint32_t layer_seed(uint32_t seed, int layer, int branch) {
+    uint32_t s = lowbias32(seed + (uint32_t)(layer + 1) * 0x9E3779B1u);
+    return lowbias32(s ^ ((uint32_t)(branch + 1) * 0x846CA68Bu));
+}
+__host__ __device__ inline uint32_t drop_threshold(float p) { return (uint32_t)(p * 16777216.0f); }
+__device__ inline bool drop_keep(uint32_t seed, uint64_t idx, uint32_t thresh) {
+    return (hash_u32(seed, idx) >> 8) >= thresh;
+}
+
+// Per-branch pointer pack passed by value to kernels (nbr <= 2).
+struct Ptr2 {
+    const float* p[2];
+};
+struct MPtr2 {
+    float* p[2];
+};
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace zns

@@ -1,0 +1,700 @@
+// fp32-MFMA implicit-GEMM convolutions for cv2..cv8 of _CNN (models.py:17-23, 41-70) on gfx950.
+//
+// Why fp32 MFMA: the parity bar is 1e-4 against the fp32 CPU reference with reductions up to
+// K = 26 880 (cv6); v_mfma_f32_32x32x2_f32 is bit-for-bit an fmaf chain, so the roofline for these
+// kernels is the dense fp32 matrix peak (157.3 TFLOP/s).  At that rate one CU consumes only
+// 2 operand dwords per lane per 64 cycles, so HBM/L2/LDS bandwidth is never the limit here; the whole
+// design goal is to keep the matrix pipe issuing back-to-back:
+//   * 8 waves (2 per SIMD) per workgroup, 96-128 accumulator VGPRs each,
+//   * LDS-DMA (global_load_lds) staging, double buffered, ONE barrier per K-stage,
+//   * operands read from LDS with immediate offsets only (no address VALU in the inner loop),
+//   * bias / max-pool(H) / ReLU / dropout / argmax (forward) and ReLU-dropout-mask / max-unpool
+//     (backward-data) fused into the accumulator epilogue, in registers.
+//
+// Forward and backward-data share one core ("conv_core"): backward-data is the same correlation with
+// the weights packed transposed+flipped.  Backward-weights ("wgrad_core") is a second GEMM whose K is
+// the pixel index; it writes split-K partial slabs that a small reducer sums in a fixed order
+// (bitwise reproducible, no float atomics).
+#include "zns_common.h"
+#include "zns_kernels.h"
+
+namespace zns {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ const float g_zero_page[16] = {0};
+
+__device__ __forceinline__ void glds4(const float* src, float* lds_dst) {
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)lds_dst, 4, 0, 0);
+}
+__device__ __forceinline__ void glds16(const float* src, float* lds_dst) {
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)lds_dst, 16, 0, 0);
+}
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// MFMA 32x32 accumulator: lane&31 = column, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+__device__ __forceinline__ int acc_row(int reg, int lane_h) { return (reg & 3) + 8 * (reg >> 2) + 4 * lane_h; }
+
+// =====================================================================================================
+//                                   forward / backward-data core
+// =====================================================================================================
+template <int CIN_, int COUT_, int KH_, int KW_, int H_, int MT_, int RT_, int CT_, int WM_, int WR_, int WC_,
+          int CK_, int POOL_, int EPI_>
+struct ConvCfg {
+    static constexpr int CIN = CIN_, COUT = COUT_, KH = KH_, KW = KW_, H = H_;
+    static constexpr int MT = MT_, RT = RT_, CT = CT_, WM = WM_, WR = WR_, WC = WC_, CK = CK_;
+    static constexpr int POOL = POOL_, EPI = EPI_;
+    static constexpr int NW = WM * WR * WC, NT = NW * 64;
+    static constexpr int COB = WM * MT * 32, RB = WR * RT, WB = WC * CT * 32;
+    static constexpr int PH = KH / 2, PW = KW / 2;
+    static constexpr int PR = RB + KH - 1, PCW = WB + KW - 1;
+    static constexpr int PS = (PR * PCW) | 1;                 // odd plane stride
+    static constexpr int PATCH = ((CK * PS + 63) / 64) * 64;  // floats per patch buffer
+    static constexpr int SLAB = CK * KW * COB;                // floats per weight stage
+    static constexpr int NCC = CIN / CK, NST = NCC * KH;
+    static constexpr int LDS_BYTES = (2 * SLAB + 2 * PATCH) * 4;
+    static constexpr int HP = H / POOL;
+    static_assert(CIN % CK == 0 && CK % 2 == 0, "CK");
+    static_assert(COUT % COB == 0, "COB");
+    static_assert(H % RB == 0, "RB");
+    static_assert(SLAB % 256 == 0, "slab must be whole 1-KiB DMA pieces");
+    static_assert(RT % POOL == 0, "pool must divide the row tiles of a wave");
+    static_assert(MT == 1 || MT == 2 || MT == 4, "MT");
+    static_assert(MT * RT * CT * 16 <= 160, "accumulator budget");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert(CK * PS * 4 < 65536, "ds_read immediate range");
+};
+
+struct CoreArgs {
+    const float* x;        // [N, CIN, H, T]
+    const float* wpk;      // packed weights, branch stride = COUT*CIN*KH*KW
+    int B, T, N;           // N = nbr*B
+    int ncb;               // column blocks
+    // EPI 0
+    Ptr2 bias;
+    float* y;
+    uint8_t* argmax;
+    uint32_t thresh;
+    float inv_keep;
+    uint32_t seed;
+    int layer;
+    // EPI 1
+    float* dx;
+    const float* xmask;
+    const uint8_t* prev_argmax;
+    int prev_pool;
+};
+
+template <class C>
+__device__ __forceinline__ void load_patch(const float* xn, int cc, int h0, int w0, int T, float* lds_patch, int wid,
+                                           int lane) {
+    constexpr int NI = C::PATCH / 64;
+    for (int q = wid; q < NI; q += C::NW) {
+        const int L = q * 64 + lane;
+        const int ci = L / C::PS;
+        const int rem = L - ci * C::PS;
+        const int row = rem / C::PCW;
+        const int col = rem - row * C::PCW;
+        const int hh = h0 - C::PH + row, ww = w0 - C::PW + col;
+        const bool ok = (ci < C::CK) && (row < C::PR) && hh >= 0 && hh < C::H && ww >= 0 && ww < T;
+        const float* src = ok ? xn + ((size_t)(cc * C::CK + ci) * C::H + hh) * T + ww : g_zero_page;
+        glds4(src, lds_patch + q * 64);
+    }
+}
+
+template <class C>
+__device__ __forceinline__ void load_slab(const float* wslab, float* lds_slab, int wid, int lane) {
+    constexpr int NI = C::SLAB / 256;
+    for (int q = wid; q < NI; q += C::NW) glds16(wslab + q * 256 + lane * 4, lds_slab + q * 256);
+}
+
+template <class C>
+__device__ __forceinline__ void compute_stage(const float* __restrict__ pa, const float* __restrict__ pb,
+                                              f32x16 (&acc)[C::MT][C::RT][C::CT]) {
+#pragma unroll
+    for (int cp = 0; cp < C::CK / 2; ++cp) {
+#pragma unroll
+        for (int s = 0; s < C::KW; ++s) {
+            float a[C::MT];
+            const float* ap = pa + (cp * C::KW + s) * (C::WM * 64 * C::MT);
+            if constexpr (C::MT == 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ap);
+                a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
+            } else if constexpr (C::MT == 2) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(ap);
+                a[0] = v[0]; a[1] = v[1];
+            } else {
+                a[0] = *ap;
+            }
+            float b[C::RT][C::CT];
+#pragma unroll
+            for (int rt = 0; rt < C::RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < C::CT; ++ct) b[rt][ct] = pb[2 * cp * C::PS + rt * C::PCW + ct * 32 + s];
+#pragma unroll
+            for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+                for (int rt = 0; rt < C::RT; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < C::CT; ++ct)
+                        acc[m][rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[rt][ct], acc[m][rt][ct], 0, 0, 0);
+        }
+    }
+}
+
+template <class C>
+__global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    auto slab = [&](int i) -> float* { return smem + (i & 1) * C::SLAB; };
+    auto patch = [&](int i) -> float* { return smem + 2 * C::SLAB + (i & 1) * C::PATCH; };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane_j = lane & 31, lane_h = lane >> 5;
+    const int wc = wid % C::WC, wr = (wid / C::WC) % C::WR, wm = wid / (C::WC * C::WR);
+
+    // block -> (column block, row block, co block, sample)
+    int bid = blockIdx.x;
+    const int cb = bid % A.ncb;
+    bid /= A.ncb;
+    const int rb = bid % (C::H / C::RB);
+    bid /= (C::H / C::RB);
+    const int cob = bid % (C::COUT / C::COB);
+    const int n = bid / (C::COUT / C::COB);
+    const int br = n / A.B;
+    const int h0 = rb * C::RB, w0 = cb * C::WB;
+    const int T = A.T;
+
+    const float* xn = A.x + (size_t)n * C::CIN * C::H * T;
+    const float* wbase = A.wpk + (size_t)br * C::COUT * C::CIN * C::KH * C::KW + (size_t)cob * C::NST * C::SLAB;
+
+    f32x16 acc[C::MT][C::RT][C::CT];
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+        for (int rt = 0; rt < C::RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < C::CT; ++ct)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[m][rt][ct][k] = 0.f;
+
+    const int abase = wm * (64 * C::MT) + lane * C::MT;
+    const int bbase = lane_h * C::PS + (wr * C::RT) * C::PCW + wc * C::CT * 32 + lane_j;
+
+    load_patch<C>(xn, 0, h0, w0, T, patch(0), wid, lane);
+    load_slab<C>(wbase, slab(0), wid, lane);
+
+    int st = 0;
+    for (int cc = 0; cc < C::NCC; ++cc) {
+        for (int r = 0; r < C::KH; ++r, ++st) {
+            wait_vm0();
+            __syncthreads();
+            if (st + 1 < C::NST) {
+                load_slab<C>(wbase + (size_t)(st + 1) * C::SLAB, slab(st + 1), wid, lane);
+                if (r == C::KH - 1) load_patch<C>(xn, cc + 1, h0, w0, T, patch(cc + 1), wid, lane);
+            }
+            compute_stage<C>(slab(st) + abase, patch(cc) + bbase + r * C::PCW, acc);
+        }
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    if constexpr (C::EPI == 0) {
+        const uint32_t lseed = layer_seed(A.seed, A.layer, br);
+        const int b_in_br = n - br * A.B;
+        const float* bias = A.bias.p[br];
+#pragma unroll
+        for (int m = 0; m < C::MT; ++m) {
+            const int co0 = cob * C::COB + (wm * C::MT + m) * 32;
+#pragma unroll
+            for (int ct = 0; ct < C::CT; ++ct) {
+                const int col = w0 + (wc * C::CT + ct) * 32 + lane_j;
+                if (col >= T) continue;
+#pragma unroll
+                for (int g = 0; g < C::RT / C::POOL; ++g) {
+                    const int hp = (h0 + wr * C::RT) / C::POOL + g;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int co = co0 + acc_row(k, lane_h);
+                        float best = acc[m][g * C::POOL][ct][k];
+                        int am = 0;
+#pragma unroll
+                        for (int a = 1; a < C::POOL; ++a) {
+                            const float v = acc[m][g * C::POOL + a][ct][k];
+                            if (v > best) { best = v; am = a; }
+                        }
+                        float v = best + bias[co];
+                        v = v > 0.f ? v : 0.f;
+                        const size_t o = (((size_t)n * C::COUT + co) * C::HP + hp) * T + col;
+                        if (A.thresh) {
+                            const uint64_t idx = (((uint64_t)b_in_br * C::COUT + co) * C::HP + hp) * T + col;
+                            v = drop_keep(lseed, idx, A.thresh) ? v * A.inv_keep : 0.f;
+                        }
+                        A.y[o] = v;
+                        if (C::POOL > 1 && A.argmax) A.argmax[o] = (uint8_t)am;
+                    }
+                }
+            }
+        }
+    } else {
+        const int pp = A.prev_pool;
+#pragma unroll
+        for (int m = 0; m < C::MT; ++m) {
+            const int co0 = cob * C::COB + (wm * C::MT + m) * 32;
+#pragma unroll
+            for (int ct = 0; ct < C::CT; ++ct) {
+                const int col = w0 + (wc * C::CT + ct) * 32 + lane_j;
+                if (col >= T) continue;
+#pragma unroll
+                for (int rt = 0; rt < C::RT; ++rt) {
+                    const int row = h0 + wr * C::RT + rt;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int co = co0 + acc_row(k, lane_h);
+                        const size_t o = (((size_t)n * C::COUT + co) * C::H + row) * T + col;
+                        float g = acc[m][rt][ct][k];
+                        if (A.xmask) g = (A.xmask[o] != 0.f) ? g * A.inv_keep : 0.f;
+                        if (pp > 1) {
+                            const int am = A.prev_argmax[o];
+                            const size_t base = (((size_t)n * C::COUT + co) * C::H + row) * pp * T + col;
+                            for (int a = 0; a < pp; ++a) A.dx[base + (size_t)a * T] = (a == am) ? g : 0.f;
+                        } else {
+                            A.dx[o] = g;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Pack OIHW weights into the stage-slab order conv_core streams:
+//   [branch][cob][stage = cc*KH + r][cp][s][wm][lane_h][i][m]
+// transposed != 0 packs the backward-data operator: Wc[co_c][ci_c][r][s] = W[ci_c][co_c][KH-1-r][KW-1-s].
+__global__ void pack_weights_kernel(Ptr2 w, float* __restrict__ dst, int cin_c, int cout_c, int kh, int kw, int cob_sz,
+                                    int ck, int mt, int wm_n, int transposed, long long per_branch, int nbr) {
+    const long long total = per_branch * nbr;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total;
+         o += (long long)gridDim.x * blockDim.x) {
+        const int br = (int)(o / per_branch);
+        long long q = o % per_branch;
+        const int m = (int)(q % mt); q /= mt;
+        const int i = (int)(q % 32); q /= 32;
+        const int h = (int)(q % 2); q /= 2;
+        const int wm = (int)(q % wm_n); q /= wm_n;
+        const int s = (int)(q % kw); q /= kw;
+        const int cp = (int)(q % (ck / 2)); q /= (ck / 2);
+        const int r = (int)(q % kh); q /= kh;
+        const int ncc = cin_c / ck;
+        const int cc = (int)(q % ncc); q /= ncc;
+        const int cob = (int)q;
+        const int co = cob * cob_sz + (wm * mt + m) * 32 + i;
+        const int ci = cc * ck + 2 * cp + h;
+        float v;
+        if (!transposed) {
+            v = w.p[br][(((size_t)co * cin_c + ci) * kh + r) * kw + s];
+        } else {
+            // original tensor is [cout_o = cin_c][cin_o = cout_c][kh][kw]
+            v = w.p[br][(((size_t)ci * cout_c + co) * kh + (kh - 1 - r)) * kw + (kw - 1 - s)];
+        }
+        dst[o] = v;
+    }
+}
+
+// =====================================================================================================
+//                                        backward-weights core
+// =====================================================================================================
+template <int CIN_, int COUT_, int KH_, int KW_, int H_, int MT_, int NS_, int WMW_, int WQ_, int R_>
+struct WgCfg {
+    static constexpr int CIN = CIN_, COUT = COUT_, KH = KH_, KW = KW_, H = H_;
+    static constexpr int MT = MT_, NS = NS_, WMW = WMW_, WQ = WQ_, R = R_;
+    static constexpr int NW = WMW * WQ, NT = NW * 64;
+    static constexpr int COB = WMW * MT * 32;
+    static constexpr int G = WQ * NS, Q = KH * KW, NQG = (Q + G - 1) / G;
+    static constexpr int CW = 64;
+    static constexpr int PH = KH / 2, PW = KW / 2;
+    static constexpr int RSPAN = (KW - 1 + G - 1) / KW + 1;
+    static constexpr int PRW = R + RSPAN - 1, PCW = CW + KW - 1;
+    static constexpr int PS = (PRW * PCW) | 1;
+    static constexpr int ZS = (R * CW) | 1;
+    static constexpr int ZBUF = ((COB * ZS + 63) / 64) * 64;
+    static constexpr int XBUF = ((32 * PS + 63) / 64) * 64;
+    static constexpr int LDS_BYTES = 2 * (ZBUF + XBUF) * 4;
+    static_assert(CIN % 32 == 0 && COUT % COB == 0 && H % R == 0, "tiling");
+    static_assert(MT * NS * 16 <= 160, "accumulator budget");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+struct WgArgs {
+    const float* dz;   // [N, COUT, H, T]
+    const float* x;    // [N, CIN, H, T]
+    float* slab;       // [nbr][KS][Q][COUT][CIN]
+    int B, T, ncb;     // column blocks of 64
+    int KS, tiles_per_split, tiles_total;   // per branch
+};
+
+template <class C>
+__device__ __forceinline__ void wg_load_tile(const WgArgs& A, int br, int cob, int cit, int r0, int tile, float* zb,
+                                             float* xb, int wid, int lane) {
+    const int T = A.T;
+    const int cbk = tile % A.ncb;
+    const int rbk = (tile / A.ncb) % (C::H / C::R);
+    const int b = tile / (A.ncb * (C::H / C::R));
+    const int n = br * A.B + b;
+    const int h0 = rbk * C::R, w0 = cbk * C::CW;
+    // dZ tile: one 64-float row segment per DMA instruction, rows of a channel ZS apart (odd stride)
+    const float* zn = A.dz + ((size_t)n * C::COUT + (size_t)cob * C::COB) * C::H * T;
+    for (int q = wid; q < C::COB * C::R; q += C::NW) {
+        const int co = q / C::R, row = q - co * C::R;
+        const int ww = w0 + lane;
+        const float* src = (ww < T) ? zn + ((size_t)co * C::H + h0 + row) * T + ww : g_zero_page;
+        glds4(src, zb + co * C::ZS + row * C::CW);
+    }
+    // X patch for 32 input channels
+    const float* xn = A.x + ((size_t)n * C::CIN + (size_t)cit * 32) * C::H * T;
+    constexpr int NI = C::XBUF / 64;
+    for (int q = wid; q < NI; q += C::NW) {
+        const int L = q * 64 + lane;
+        const int ci = L / C::PS;
+        const int rem = L - ci * C::PS;
+        const int row = rem / C::PCW;
+        const int col = rem - row * C::PCW;
+        const int hh = h0 + r0 - C::PH + row, ww = w0 - C::PW + col;
+        const bool ok = (ci < 32) && (row < C::PRW) && hh >= 0 && hh < C::H && ww >= 0 && ww < T;
+        const float* src = ok ? xn + ((size_t)ci * C::H + hh) * T + ww : g_zero_page;
+        glds4(src, xb + q * 64);
+    }
+}
+
+template <class C>
+__global__ void __launch_bounds__(C::NT) wgrad_core(WgArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    auto zbuf = [&](int i) -> float* { return smem + (i & 1) * C::ZBUF; };
+    auto xbuf = [&](int i) -> float* { return smem + 2 * C::ZBUF + (i & 1) * C::XBUF; };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane_j = lane & 31, lane_h = lane >> 5;
+    const int wq = wid % C::WQ, wmw = wid / C::WQ;
+
+    int bid = blockIdx.x;
+    const int qg = bid % C::NQG; bid /= C::NQG;
+    const int cit = bid % (C::CIN / 32); bid /= (C::CIN / 32);
+    const int cob = bid % (C::COUT / C::COB); bid /= (C::COUT / C::COB);
+    const int ks = bid % A.KS;
+    const int br = bid / A.KS;
+
+    const int q0 = qg * C::G;
+    const int r0 = q0 / C::KW;
+    const int t_begin = ks * A.tiles_per_split;
+    int t_end = t_begin + A.tiles_per_split;
+    if (t_end > A.tiles_total) t_end = A.tiles_total;
+
+    f32x16 acc[C::MT][C::NS];
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[m][s][k] = 0.f;
+
+    // per-lane LDS bases
+    const int zbase = ((wmw * C::MT) * 32 + lane_j) * C::ZS + lane_h;
+    int xoff[C::NS];
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s) {
+        int q = q0 + wq * C::NS + s;
+        if (q >= C::Q) q = C::Q - 1;   // padded shift: computed, never stored
+        const int rr = q / C::KW, ss = q - rr * C::KW;
+        xoff[s] = lane_j * C::PS + (rr - r0) * C::PCW + ss + lane_h;
+    }
+
+    if (t_begin < t_end) wg_load_tile<C>(A, br, cob, cit, r0, t_begin, zbuf(0), xbuf(0), wid, lane);
+    int cur = 0;
+    for (int tile = t_begin; tile < t_end; ++tile, cur ^= 1) {
+        wait_vm0();
+        __syncthreads();
+        if (tile + 1 < t_end) wg_load_tile<C>(A, br, cob, cit, r0, tile + 1, zbuf(cur ^ 1), xbuf(cur ^ 1), wid, lane);
+        const float* __restrict__ zp = zbuf(cur) + zbase;
+        const float* __restrict__ xp = xbuf(cur);
+#pragma unroll
+        for (int prow = 0; prow < C::R; ++prow) {
+#pragma unroll
+            for (int pc = 0; pc < C::CW / 2; ++pc) {
+                float a[C::MT], b[C::NS];
+#pragma unroll
+                for (int m = 0; m < C::MT; ++m) a[m] = zp[m * 32 * C::ZS + prow * C::CW + 2 * pc];
+#pragma unroll
+                for (int s = 0; s < C::NS; ++s) b[s] = xp[xoff[s] + prow * C::PCW + 2 * pc];
+#pragma unroll
+                for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+                    for (int s = 0; s < C::NS; ++s)
+                        acc[m][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[s], acc[m][s], 0, 0, 0);
+            }
+        }
+    }
+
+    // partial slab: [br][ks][q][co][ci]
+    float* sl = A.slab + ((size_t)br * A.KS + ks) * C::Q * C::COUT * C::CIN;
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s) {
+        const int q = q0 + wq * C::NS + s;
+        if (q >= C::Q) continue;
+#pragma unroll
+        for (int m = 0; m < C::MT; ++m) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int co = cob * C::COB + (wmw * C::MT + m) * 32 + acc_row(k, lane_h);
+                const int ci = cit * 32 + lane_j;
+                sl[((size_t)q * C::COUT + co) * C::CIN + ci] = acc[m][s][k];
+            }
+        }
+    }
+}
+
+// dw[br][co][ci][r][s] (+)= sum_ks slab[br][ks][q=r*KW+s][co][ci], fixed summation order
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, MPtr2 dw, int KS, int Q, int cout, int cin,
+                                    int accumulate, int nbr) {
+    const long long per = (long long)Q * cout * cin;
+    const long long total = per * nbr;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total;
+         o += (long long)gridDim.x * blockDim.x) {
+        const int br = (int)(o / per);
+        const long long e = o % per;
+        const int ci = (int)(e % cin);
+        const int co = (int)((e / cin) % cout);
+        const int q = (int)(e / ((long long)cin * cout));
+        const float* sp = slab + (size_t)br * KS * per + e;
+        float s = 0.f;
+        for (int k = 0; k < KS; ++k) s += sp[(size_t)k * per];
+        float* d = dw.p[br] + ((size_t)co * cin + ci) * Q + q;
+        *d = accumulate ? *d + s : s;
+    }
+}
+
+// =====================================================================================================
+//                                          instances + dispatch
+// =====================================================================================================
+//                 CIN COUT KH KW  H  MT RT CT WM WR WC CK POOL EPI
+using F2 = ConvCfg<64, 64, 7, 13, 96, 2, 3, 1, 1, 2, 4, 4, 3, 0>;
+using F3 = ConvCfg<64, 128, 5, 15, 32, 4, 2, 1, 1, 2, 4, 4, 1, 0>;
+using F4 = ConvCfg<128, 128, 9, 17, 32, 2, 4, 1, 2, 1, 4, 4, 4, 0>;
+using F5 = ConvCfg<128, 256, 3, 19, 8, 4, 2, 1, 2, 2, 2, 2, 1, 0>;
+using F6 = ConvCfg<256, 256, 5, 21, 8, 1, 8, 1, 8, 1, 1, 2, 8, 0>;
+using F7 = ConvCfg<256, 128, 1, 23, 1, 2, 1, 1, 2, 1, 2, 4, 1, 0>;
+using F8 = ConvCfg<128, 128, 1, 25, 1, 2, 1, 1, 2, 1, 2, 4, 1, 0>;
+// backward-data: core CIN = conv cout, core COUT = conv cin
+using D2 = ConvCfg<64, 64, 7, 13, 96, 2, 3, 1, 1, 2, 4, 4, 1, 1>;
+using D3 = ConvCfg<128, 64, 5, 15, 32, 2, 4, 1, 1, 2, 4, 4, 1, 1>;
+using D4 = ConvCfg<128, 128, 9, 17, 32, 2, 4, 1, 2, 1, 4, 4, 1, 1>;
+using D5 = ConvCfg<256, 128, 3, 19, 8, 4, 2, 1, 1, 4, 2, 4, 1, 1>;
+using D6 = ConvCfg<256, 256, 5, 21, 8, 4, 2, 1, 2, 4, 1, 2, 1, 1>;
+using D7 = ConvCfg<128, 256, 1, 23, 1, 4, 1, 1, 2, 1, 2, 2, 1, 1>;
+using D8 = ConvCfg<128, 128, 1, 25, 1, 2, 1, 1, 2, 1, 2, 4, 1, 1>;
+//                CIN COUT KH KW  H  MT NS WMW WQ R
+using W2 = WgCfg<64, 64, 7, 13, 96, 2, 4, 1, 8, 1>;
+using W3 = WgCfg<64, 128, 5, 15, 32, 2, 4, 2, 4, 1>;
+using W4 = WgCfg<128, 128, 9, 17, 32, 2, 4, 2, 4, 1>;
+using W5 = WgCfg<128, 256, 3, 19, 8, 2, 4, 2, 4, 1>;
+using W6 = WgCfg<256, 256, 5, 21, 8, 2, 4, 2, 4, 1>;
+using W7 = WgCfg<256, 128, 1, 23, 1, 2, 3, 2, 4, 1>;
+using W8 = WgCfg<128, 128, 1, 25, 1, 2, 4, 2, 4, 1>;
+
+static int layer_of(const ConvArgs& a) {
+    struct L { int cin, cout, kh, kw, H; };
+    static const L tab[] = {{64, 64, 7, 13, 96},  {64, 128, 5, 15, 32}, {128, 128, 9, 17, 32}, {128, 256, 3, 19, 8},
+                            {256, 256, 5, 21, 8}, {256, 128, 1, 23, 1}, {128, 128, 1, 25, 1}};
+    for (int i = 0; i < 7; ++i)
+        if (tab[i].cin == a.cin && tab[i].cout == a.cout && tab[i].kh == a.kh && tab[i].kw == a.kw && tab[i].H == a.H)
+            return i + 2;
+    return -1;
+}
+
+bool mfma_supported(const ConvArgs& a) { return layer_of(a) > 0 && a.nbr >= 1 && a.nbr <= 2; }
+
+template <class C>
+static int wg_pick_ks(const ConvArgs& a, int* tiles_total, int* tps) {
+    const int ncb = ceil_div(a.T, C::CW);
+    const int total = a.B * (C::H / C::R) * ncb;
+    const int base = C::NQG * (C::CIN / 32) * (C::COUT / C::COB) * a.nbr;
+    int ks = ceil_div(1024, base);
+    if (ks > total) ks = total;
+    if (ks < 1) ks = 1;
+    const int per = ceil_div(total, ks);
+    ks = ceil_div(total, per);
+    *tiles_total = total;
+    *tps = per;
+    return ks;
+}
+
+template <class C>
+static size_t wg_slab_bytes(const ConvArgs& a) {
+    int tt, tps;
+    const int ks = wg_pick_ks<C>(a, &tt, &tps);
+    return (size_t)a.nbr * ks * C::Q * C::COUT * C::CIN * sizeof(float);
+}
+
+static size_t packed_bytes(const ConvArgs& a) {
+    return (size_t)a.nbr * a.cout * a.cin * a.kh * a.kw * sizeof(float);
+}
+
+size_t mfma_workspace_bytes(const ConvArgs& a) {
+    size_t slab = 0;
+    switch (layer_of(a)) {
+        case 2: slab = wg_slab_bytes<W2>(a); break;
+        case 3: slab = wg_slab_bytes<W3>(a); break;
+        case 4: slab = wg_slab_bytes<W4>(a); break;
+        case 5: slab = wg_slab_bytes<W5>(a); break;
+        case 6: slab = wg_slab_bytes<W6>(a); break;
+        case 7: slab = wg_slab_bytes<W7>(a); break;
+        case 8: slab = wg_slab_bytes<W8>(a); break;
+        default: return 0;
+    }
+    const size_t pk = (packed_bytes(a) + 255) & ~(size_t)255;
+    return pk > slab ? pk : slab;
+}
+
+template <class C>
+static int set_lds(void (*kern)(CoreArgs)) {
+    static bool done = false;
+    if (!done) {
+        ZNS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        done = true;
+    }
+    return ZNS_OK;
+}
+template <class C>
+static int set_lds_wg(void (*kern)(WgArgs)) {
+    static bool done = false;
+    if (!done) {
+        ZNS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        done = true;
+    }
+    return ZNS_OK;
+}
+
+template <class C>
+static int pack_for(const ConvArgs& a, Ptr2 w, float* dst, int transposed, hipStream_t st) {
+    const long long per_branch = (long long)C::COUT * C::CIN * C::KH * C::KW;
+    const long long total = per_branch * a.nbr;
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, st, w, dst, C::CIN, C::COUT, C::KH, C::KW,
+                       C::COB, C::CK, C::MT, C::WM, transposed, per_branch, a.nbr);
+    ZNS_LAUNCH_CHECK();
+    return ZNS_OK;
+}
+
+template <class C>
+static int launch_core(const ConvArgs& a, CoreArgs A, Ptr2 w, int transposed, void* ws, size_t ws_bytes,
+                       hipStream_t st) {
+    if (ws_bytes < packed_bytes(a)) {
+        set_error("conv: workspace %zu < %zu", ws_bytes, packed_bytes(a));
+        return ZNS_ERR_WORKSPACE;
+    }
+    int rc = pack_for<C>(a, w, (float*)ws, transposed, st);
+    if (rc) return rc;
+    rc = set_lds<C>(conv_core<C>);
+    if (rc) return rc;
+    A.wpk = (const float*)ws;
+    A.B = a.B;
+    A.T = a.T;
+    A.N = a.nbr * a.B;
+    A.ncb = ceil_div(a.T, C::WB);
+    const long long blocks = (long long)A.N * (C::H / C::RB) * A.ncb * (C::COUT / C::COB);
+    hipLaunchKernelGGL(conv_core<C>, dim3((unsigned)blocks), dim3(C::NT), C::LDS_BYTES, st, A);
+    ZNS_LAUNCH_CHECK();
+    return ZNS_OK;
+}
+
+int mfma_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, uint8_t* argmax, float drop_p,
+             uint32_t seed, int layer, void* ws, size_t ws_bytes, hipStream_t st) {
+    CoreArgs A{};
+    A.x = x;
+    A.bias = bias;
+    A.y = y;
+    A.argmax = argmax;
+    A.thresh = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
+    A.inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
+    A.seed = seed;
+    A.layer = layer;
+    switch (layer_of(a)) {
+        case 2: return launch_core<F2>(a, A, w, 0, ws, ws_bytes, st);
+        case 3: return launch_core<F3>(a, A, w, 0, ws, ws_bytes, st);
+        case 4: return launch_core<F4>(a, A, w, 0, ws, ws_bytes, st);
+        case 5: return launch_core<F5>(a, A, w, 0, ws, ws_bytes, st);
+        case 6: return launch_core<F6>(a, A, w, 0, ws, ws_bytes, st);
+        case 7: return launch_core<F7>(a, A, w, 0, ws, ws_bytes, st);
+        case 8: return launch_core<F8>(a, A, w, 0, ws, ws_bytes, st);
+    }
+    return ZNS_ERR_ARG;
+}
+
+int mfma_dgrad(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, const float* x, float inv_keep,
+               const uint8_t* prev_argmax, int prev_pool, void* ws, size_t ws_bytes, hipStream_t st) {
+    CoreArgs A{};
+    A.x = dz;
+    A.dx = dx;
+    A.xmask = x;
+    A.inv_keep = inv_keep;
+    A.prev_argmax = prev_argmax;
+    A.prev_pool = prev_pool;
+    switch (layer_of(a)) {
+        case 2: return launch_core<D2>(a, A, w, 1, ws, ws_bytes, st);
+        case 3: return launch_core<D3>(a, A, w, 1, ws, ws_bytes, st);
+        case 4: return launch_core<D4>(a, A, w, 1, ws, ws_bytes, st);
+        case 5: return launch_core<D5>(a, A, w, 1, ws, ws_bytes, st);
+        case 6: return launch_core<D6>(a, A, w, 1, ws, ws_bytes, st);
+        case 7: return launch_core<D7>(a, A, w, 1, ws, ws_bytes, st);
+        case 8: return launch_core<D8>(a, A, w, 1, ws, ws_bytes, st);
+    }
+    return ZNS_ERR_ARG;
+}
+
+template <class C>
+static int launch_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, int accumulate, void* ws,
+                        size_t ws_bytes, hipStream_t st) {
+    WgArgs A{};
+    A.dz = dz;
+    A.x = x;
+    A.slab = (float*)ws;
+    A.B = a.B;
+    A.T = a.T;
+    A.ncb = ceil_div(a.T, C::CW);
+    A.KS = wg_pick_ks<C>(a, &A.tiles_total, &A.tiles_per_split);
+    const size_t need = (size_t)a.nbr * A.KS * C::Q * C::COUT * C::CIN * sizeof(float);
+    if (ws_bytes < need) {
+        set_error("wgrad: workspace %zu < %zu", ws_bytes, need);
+        return ZNS_ERR_WORKSPACE;
+    }
+    int rc = set_lds_wg<C>(wgrad_core<C>);
+    if (rc) return rc;
+    const long long blocks = (long long)C::NQG * (C::CIN / 32) * (C::COUT / C::COB) * A.KS * a.nbr;
+    hipLaunchKernelGGL(wgrad_core<C>, dim3((unsigned)blocks), dim3(C::NT), C::LDS_BYTES, st, A);
+    ZNS_LAUNCH_CHECK();
+    const long long total = (long long)a.nbr * C::Q * C::COUT * C::CIN;
+    const int rblocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, st, (const float*)ws, dw, A.KS, C::Q, C::COUT,
+                       C::CIN, accumulate, a.nbr);
+    ZNS_LAUNCH_CHECK();
+    return ZNS_OK;
+}
+
+int mfma_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, int accumulate, void* ws,
+               size_t ws_bytes, hipStream_t st) {
+    switch (layer_of(a)) {
+        case 2: return launch_wgrad<W2>(a, dz, x, dw, accumulate, ws, ws_bytes, st);
+        case 3: return launch_wgrad<W3>(a, dz, x, dw, accumulate, ws, ws_bytes, st);
+        case 4: return launch_wgrad<W4>(a, dz, x, dw, accumulate, ws, ws_bytes, st);
+        case 5: return launch_wgrad<W5>(a, dz, x, dw, accumulate, ws, ws_bytes, st);
+        case 6: return launch_wgrad<W6>(a, dz, x, dw, accumulate, ws, ws_bytes, st);
+        case 7: return launch_wgrad<W7>(a, dz, x, dw, accumulate, ws, ws_bytes, st);
+        case 8: return launch_wgrad<W8>(a, dz, x, dw, accumulate, ws, ws_bytes, st);
+    }
+    return ZNS_ERR_ARG;
+}
+
+}  // namespace zns

@@ -1,0 +1,36 @@
+// Internal launcher declarations shared by the translation units of libzns_hip.so.
+#pragma once
+#include "zns_common.h"
+
+namespace zns {
+
+struct ConvArgs {
+    int nbr, B, T, cin, cout, kh, kw, H, pool;
+};
+
+// zns_naive.hip
+int naive_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, uint8_t* argmax, float drop_p,
+              uint32_t seed, int layer, hipStream_t st);
+int naive_dgrad(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, const float* x, float inv_keep,
+                const uint8_t* prev_argmax, int prev_pool, hipStream_t st);
+int naive_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, int accumulate, hipStream_t st);
+int channel_sum(int nbr, int B, int C, long long HT, const float* dz, MPtr2 db, int accumulate, hipStream_t st);
+
+// zns_conv_mfma.hip -- return ZNS_ERR_ARG (without setting an error) when the shape has no instance
+bool mfma_supported(const ConvArgs& a);
+size_t mfma_workspace_bytes(const ConvArgs& a);
+int mfma_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, uint8_t* argmax, float drop_p,
+             uint32_t seed, int layer, void* ws, size_t ws_bytes, hipStream_t st);
+int mfma_dgrad(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, const float* x, float inv_keep,
+               const uint8_t* prev_argmax, int prev_pool, void* ws, size_t ws_bytes, hipStream_t st);
+int mfma_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, int accumulate, void* ws,
+               size_t ws_bytes, hipStream_t st);
+
+// zns_cv1.hip -- direct (HBM-bound) kernels for the cin==1 first layer
+int cv1_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, float drop_p, uint32_t seed,
+            int layer, hipStream_t st);
+int cv1_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, MPtr2 db, int accumulate, void* ws,
+              size_t ws_bytes, hipStream_t st);
+size_t cv1_workspace_bytes(const ConvArgs& a);
+
+}  // namespace zns

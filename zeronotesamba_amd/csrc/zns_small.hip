@@ -1,0 +1,372 @@
+// Small fused kernels around the conv stack: DS_CNN head (fc1 + sigmoid), Down_CNN combine,
+// NT-Xent forward+backward, BCE, fused Adam, on-device shift batching.
+// All are HBM- or latency-bound; the design points are coalesced 16-B accesses along T and
+// wavefront (64-lane) shuffle reductions.
+#include "zns_common.h"
+#include "zns_kernels.h"
+
+namespace zns {
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// block-wide sum for blockDim.x <= 1024; red must hold 16 floats; result broadcast to all threads
+__device__ inline float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += red[i];
+    return r;
+}
+
+// ------------------------------------------------------------------ head (models.py:99-101)
+__global__ void head_fwd_kernel(int B, int T, int C, const float* __restrict__ h, Ptr2 w, Ptr2 b,
+                                float* __restrict__ emb, int total) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= total) return;
+    const int t = o % T, n = o / T, br = n / B;
+    const float* hp = h + (size_t)n * C * T + t;
+    const float* wp = w.p[br];
+    float acc = 0.f;
+    for (int c = 0; c < C; ++c) acc = fmaf(hp[(size_t)c * T], wp[c], acc);
+    acc += b.p[br][0];
+    emb[o] = 1.0f / (1.0f + expf(-acc));
+}
+
+// one block per (n, c): writes dz row, partial dw; c==0 block also writes the partial db
+__global__ void head_bwd_kernel(int B, int T, int C, const float* __restrict__ h, const float* __restrict__ emb,
+                                const float* __restrict__ demb, Ptr2 w, float inv_keep, float* __restrict__ dz,
+                                float* __restrict__ part_w, float* __restrict__ part_b) {
+    __shared__ float red[16];
+    const int c = blockIdx.x % C, n = blockIdx.x / C, br = n / B;
+    const float wc = w.p[br][c];
+    const float* hp = h + ((size_t)n * C + c) * T;
+    float* zp = dz + ((size_t)n * C + c) * T;
+    float sw = 0.f, sb = 0.f;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) {
+        const float e = emb[(size_t)n * T + t];
+        const float dpre = demb[(size_t)n * T + t] * e * (1.0f - e);
+        const float hv = hp[t];
+        sw = fmaf(dpre, hv, sw);
+        sb += dpre;
+        zp[t] = (hv != 0.f) ? dpre * wc * inv_keep : 0.f;
+    }
+    sw = block_sum(sw, red);
+    if (threadIdx.x == 0) part_w[(size_t)n * C + c] = sw;
+    if (c == 0) {
+        sb = block_sum(sb, red);
+        if (threadIdx.x == 0) part_b[n] = sb;
+    }
+}
+
+__global__ void head_bwd_reduce(int B, int C, const float* __restrict__ part_w, const float* __restrict__ part_b,
+                                MPtr2 dw, MPtr2 db, int accumulate, int nbr) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= nbr * (C + 1)) return;
+    const int br = o / (C + 1), c = o % (C + 1);
+    float s = 0.f;
+    if (c < C) {
+        for (int b = 0; b < B; ++b) s += part_w[(size_t)(br * B + b) * C + c];
+        float* d = dw.p[br] + c;
+        *d = accumulate ? *d + s : s;
+    } else {
+        for (int b = 0; b < B; ++b) s += part_b[br * B + b];
+        float* d = db.p[br];
+        *d = accumulate ? *d + s : s;
+    }
+}
+
+// ------------------------------------------------------------------ Down_CNN combine (models.py:144-148)
+__global__ void down_fwd_kernel(const float* __restrict__ a, const float* __restrict__ p, size_t n, int reduction,
+                                float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float x = a[i], y = p[i];
+        out[i] = reduction == ZNS_REDUCE_MEAN ? (x + y) / 2.0f : fmaxf(x, y);
+    }
+}
+__global__ void down_bwd_kernel(const float* __restrict__ a, const float* __restrict__ p,
+                                const float* __restrict__ dout, size_t n, int reduction, float* __restrict__ da,
+                                float* __restrict__ dp) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float g = dout[i];
+        if (reduction == ZNS_REDUCE_MEAN) {
+            da[i] = g * 0.5f;
+            dp[i] = g * 0.5f;
+        } else {  // torch.maximum backward: ties split the gradient evenly
+            const float x = a[i], y = p[i];
+            da[i] = x > y ? g : (x == y ? g * 0.5f : 0.f);
+            dp[i] = y > x ? g : (x == y ? g * 0.5f : 0.f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ NT-Xent (loss_functions.py:24-55)
+// One 1024-thread block.  rows <= 32.  C = Ah Ph^T in LDS, row softmax, analytic gradient.
+#define NTX_MAXR 32
+__global__ void __launch_bounds__(1024) ntxent_kernel(const float* __restrict__ a, const float* __restrict__ p,
+                                                      int R, int D, int batch_len, float tau,
+                                                      float* __restrict__ out3, float* __restrict__ ga,
+                                                      float* __restrict__ gp, float grad_scale) {
+    __shared__ float na[NTX_MAXR], npn[NTX_MAXR];
+    __shared__ float Cm[NTX_MAXR][NTX_MAXR + 1];
+    __shared__ float Gm[NTX_MAXR][NTX_MAXR + 1];
+    __shared__ float sa[NTX_MAXR], sp[NTX_MAXR];
+    __shared__ float red[NTX_MAXR];
+    __shared__ float red1[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float eps = 1e-8f;
+    // 1. norms: wave w handles rows w, w+16, ...
+    for (int i = wid; i < 2 * R; i += 16) {
+        const float* v = (i < R) ? a + (size_t)i * D : p + (size_t)(i - R) * D;
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) s = fmaf(v[d], v[d], s);
+        s = wave_sum(s);
+        if (lane == 0) {
+            const float nrm = fmaxf(sqrtf(s), eps);
+            if (i < R) na[i] = nrm; else npn[i - R] = nrm;
+        }
+    }
+    __syncthreads();
+    // 2. cosine matrix: wave w handles pairs w, w+16, ...
+    for (int q = wid; q < R * R; q += 16) {
+        const int i = q / R, j = q % R;
+        const float* av = a + (size_t)i * D;
+        const float* pv = p + (size_t)j * D;
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) s = fmaf(av[d], pv[d], s);
+        s = wave_sum(s);
+        if (lane == 0) Cm[i][j] = s / (na[i] * npn[j]);
+    }
+    __syncthreads();
+    // 3. row softmax / loss / dL/dC ; tiny, done by the first R threads
+    if (tid < R) {
+        const int i = tid;
+        float m = -INFINITY;
+        for (int j = 0; j < R; ++j) m = fmaxf(m, Cm[i][j] / tau);
+        float z = 0.f;
+        for (int j = 0; j < R; ++j) z += expf(Cm[i][j] / tau - m);
+        const float li = (m + logf(z)) - Cm[i][i] / tau;
+        float rs = 0.f;
+        for (int j = 0; j < R; ++j) {
+            const float e = expf(Cm[i][j] / tau - m) / z;
+            Gm[i][j] = (e - (i == j ? 1.f : 0.f)) * grad_scale / (tau * (float)batch_len);
+            rs += Cm[i][j];
+        }
+        sa[i] = li;                                    // reuse as scratch for the three sums
+        sp[i] = Cm[i][i];
+        red[i] = (rs - Cm[i][i]) / (float)(batch_len - 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double l = 0, ps = 0, ns = 0;  // the reference accumulates the two cosines as Python floats (f64)
+        float lf = 0.f;
+        for (int i = 0; i < R; ++i) { lf += sa[i]; ps += sp[i]; ns += red[i]; }
+        l = lf;
+        out3[0] = (float)(l / batch_len);
+        out3[1] = (float)(ps / batch_len);
+        out3[2] = (float)(ns / batch_len);
+    }
+    if (ga == nullptr && gp == nullptr) return;
+    __syncthreads();
+    // 4./5. per anchor row i:  gah_i[d] = sum_j G[i][j] ph_j[d];  ga_i = (gah_i - ah_i (gah_i . ah_i)) / |a_i|
+    //        (and the same for the positives with G^T).  Two sweeps over d: dot product, then write.
+    for (int i = 0; i < R; ++i) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int d = tid; d < D; d += 1024) {
+            float g1 = 0.f, g2 = 0.f;
+            for (int j = 0; j < R; ++j) {
+                g1 = fmaf(Gm[i][j], p[(size_t)j * D + d] / npn[j], g1);
+                g2 = fmaf(Gm[j][i], a[(size_t)j * D + d] / na[j], g2);
+            }
+            s1 = fmaf(g1, a[(size_t)i * D + d] / na[i], s1);
+            s2 = fmaf(g2, p[(size_t)i * D + d] / npn[i], s2);
+        }
+        s1 = block_sum(s1, red1);
+        s2 = block_sum(s2, red1);
+        for (int d = tid; d < D; d += 1024) {
+            float g1 = 0.f, g2 = 0.f;
+            for (int j = 0; j < R; ++j) {
+                g1 = fmaf(Gm[i][j], p[(size_t)j * D + d] / npn[j], g1);
+                g2 = fmaf(Gm[j][i], a[(size_t)j * D + d] / na[j], g2);
+            }
+            if (ga) ga[(size_t)i * D + d] = (g1 - (a[(size_t)i * D + d] / na[i]) * s1) / na[i];
+            if (gp) gp[(size_t)i * D + d] = (g2 - (p[(size_t)i * D + d] / npn[i]) * s2) / npn[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ BCELoss (loader.py:16)
+__global__ void __launch_bounds__(1024) bce_kernel(const float* __restrict__ o, const float* __restrict__ t,
+                                                   size_t n, float* __restrict__ loss, float* __restrict__ dout,
+                                                   float grad_scale) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (size_t i = threadIdx.x; i < n; i += 1024) {
+        const float x = o[i], y = t[i];
+        const float l1 = fmaxf(logf(x), -100.f), l0 = fmaxf(logf(1.f - x), -100.f);  // ATen clamps the logs at -100
+        s -= y * l1 + (1.f - y) * l0;
+        if (dout) dout[i] = grad_scale * (x - y) / fmaxf((1.f - x) * x, 1e-12f) / (float)n;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) *loss = s / (float)n;
+}
+
+// ------------------------------------------------------------------ Adam (torch.optim.Adam defaults)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, size_t n, float b1, float b2, float eps, float step_size,
+                            float sqrt_bc2, float grad_scale) {
+    const size_t n4 = n / 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        float* pf = &pp.x; const float* gf = &gg.x; float* mf = &mm.x; float* vf = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = gf[k] * grad_scale;
+            mf[k] = mf[k] + (gk - mf[k]) * (1.f - b1);          // exp_avg.lerp_(grad, 1-beta1)
+            vf[k] = vf[k] * b2 + (1.f - b2) * gk * gk;          // mul_(beta2).addcmul_(g, g, 1-beta2)
+            const float denom = sqrtf(vf[k]) / sqrt_bc2 + eps;
+            pf[k] = pf[k] - step_size * (mf[k] / denom);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    // tail
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float gk = g[i] * grad_scale;
+        const float mk = m[i] + (gk - m[i]) * (1.f - b1);
+        const float vk = v[i] * b2 + (1.f - b2) * gk * gk;
+        m[i] = mk;
+        v[i] = vk;
+        p[i] = p[i] - step_size * (mk / (sqrtf(vk) / sqrt_bc2 + eps));
+    }
+}
+
+// ------------------------------------------------------------------ shift batching (pretext.py:308-318)
+__global__ void shift_gather_kernel(const float* __restrict__ bank, int bank_T, const int32_t* __restrict__ clip,
+                                    const int32_t* __restrict__ start, int n_items, int T,
+                                    float* __restrict__ out) {
+    // grid: (rows = 2*n_items*96), threads over T
+    const int row = blockIdx.x;
+    const int f = row % 96;
+    const int i = (row / 96) % n_items;
+    const int br = row / (96 * n_items);
+    const float* src = bank + (((size_t)clip[i] * 2 + br) * 96 + f) * bank_T + start[i];
+    float* dst = out + (size_t)row * T;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) dst[t] = src[t];
+}
+
+}  // namespace zns
+
+using namespace zns;
+
+extern "C" {
+
+int zns_head_fwd_f32(int nbr, int B, int T, int C, const float* h, const float* const* w, const float* const* b,
+                     float* emb, void* stream) {
+    ZNS_CHECK_ARG(nbr >= 1 && nbr <= 2 && B > 0 && T > 0 && C > 0, "head_fwd: bad shape");
+    Ptr2 pw{}, pb{};
+    for (int i = 0; i < nbr; ++i) { pw.p[i] = w[i]; pb.p[i] = b[i]; }
+    const int total = nbr * B * T;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, T, C, h, pw,
+                       pb, emb, total);
+    ZNS_LAUNCH_CHECK();
+    return ZNS_OK;
+}
+
+int zns_head_bwd_f32(int nbr, int B, int T, int C, const float* h, const float* emb, const float* demb,
+                     const float* const* w, float inv_keep, float* dz, float* const* dw, float* const* db,
+                     int accumulate, void* ws, size_t ws_bytes, void* stream) {
+    ZNS_CHECK_ARG(nbr >= 1 && nbr <= 2 && B > 0 && T > 0 && C > 0, "head_bwd: bad shape");
+    const size_t need = ((size_t)nbr * B * C + (size_t)nbr * B) * sizeof(float);
+    if (ws_bytes < need) { set_error("head_bwd: workspace %zu < %zu", ws_bytes, need); return ZNS_ERR_WORKSPACE; }
+    Ptr2 pw{}; MPtr2 pdw{}, pdb{};
+    for (int i = 0; i < nbr; ++i) { pw.p[i] = w[i]; pdw.p[i] = dw[i]; pdb.p[i] = db[i]; }
+    float* part_w = (float*)ws;
+    float* part_b = part_w + (size_t)nbr * B * C;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(nbr * B * C), dim3(128), 0, st, B, T, C, h, emb, demb, pw, inv_keep, dz,
+                       part_w, part_b);
+    ZNS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(head_bwd_reduce, dim3((nbr * (C + 1) + 127) / 128), dim3(128), 0, st, B, C, part_w, part_b,
+                       pdw, pdb, accumulate, nbr);
+    ZNS_LAUNCH_CHECK();
+    return ZNS_OK;
+}
+
+int zns_down_fwd_f32(const float* a, const float* p, size_t n, int reduction, float* out, void* stream) {
+    ZNS_CHECK_ARG(reduction == ZNS_REDUCE_MAX || reduction == ZNS_REDUCE_MEAN, "down_fwd: bad reduction");
+    const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(down_fwd_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, (hipStream_t)stream, a, p, n,
+                       reduction, out);
+    ZNS_LAUNCH_CHECK();
+    return ZNS_OK;
+}
+
+int zns_down_bwd_f32(const float* a, const float* p, const float* dout, size_t n, int reduction, float* da, float* dp,
+                     void* stream) {
+    ZNS_CHECK_ARG(reduction == ZNS_REDUCE_MAX || reduction == ZNS_REDUCE_MEAN, "down_bwd: bad reduction");
+    const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(down_bwd_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, (hipStream_t)stream, a, p, dout, n,
+                       reduction, da, dp);
+    ZNS_LAUNCH_CHECK();
+    return ZNS_OK;
+}
+
+int zns_ntxent_f32(const float* a, const float* p, int rows, int D, int batch_len, float tau, float* out3, float* ga,
+                   float* gp, float grad_scale, void* stream) {
+    ZNS_CHECK_ARG(rows >= 1 && rows <= NTX_MAXR, "ntxent: rows=%d not in [1,%d]", rows, NTX_MAXR);
+    ZNS_CHECK_ARG(D >= 1 && batch_len >= 2 && rows <= batch_len, "ntxent: bad D/batch_len");
+    hipLaunchKernelGGL(ntxent_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, p, rows, D, batch_len, tau,
+                       out3, ga, gp, grad_scale);
+    ZNS_LAUNCH_CHECK();
+    return ZNS_OK;
+}
+
+int zns_bce_f32(const float* out, const float* target, size_t n, float* loss, float* dout, float grad_scale,
+                void* stream) {
+    ZNS_CHECK_ARG(n > 0, "bce: empty input");
+    hipLaunchKernelGGL(bce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, out, target, n, loss, dout,
+                       grad_scale);
+    ZNS_LAUNCH_CHECK();
+    return ZNS_OK;
+}
+
+int zns_adam_step_f32(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                      float eps, int step, float grad_scale, void* stream) {
+    ZNS_CHECK_ARG(step >= 1, "adam: step must be >= 1");
+    ZNS_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
+                  "adam: buffers must be 16-byte aligned");
+    if (n == 0) return ZNS_OK;
+    const double bc1 = 1.0 - pow((double)beta1, step);
+    const double bc2 = 1.0 - pow((double)beta2, step);
+    const float step_size = (float)((double)lr / bc1);
+    const float sqrt_bc2 = (float)sqrt(bc2);
+    const size_t want = (n / 4 + 255) / 256;
+    const int blocks = (int)(want > 4096 ? 4096 : (want ? want : 1));
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, beta1, beta2, eps,
+                       step_size, sqrt_bc2, grad_scale);
+    ZNS_LAUNCH_CHECK();
+    return ZNS_OK;
+}
+
+int zns_shift_gather_f32(const float* bank, int bank_T, const int32_t* clip, const int32_t* start, int n_items,
+                         int T, float* out, void* stream) {
+    ZNS_CHECK_ARG(n_items > 0 && T > 0 && bank_T >= T, "shift_gather: bad shape");
+    hipLaunchKernelGGL(shift_gather_kernel, dim3(2 * n_items * 96), dim3(128), 0, (hipStream_t)stream, bank, bank_T,
+                       clip, start, n_items, T, out);
+    ZNS_LAUNCH_CHECK();
+    return ZNS_OK;
+}
+
+}  // extern "C"
