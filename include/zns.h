@@ -49,6 +49,13 @@ int zns_version(void);
 /* Select the kernel family for conv fwd/dgrad/wgrad (process global).  Returns the previous value. */
 int zns_set_impl(int impl);
 
+/* Measurement hook for bench.py: record hipEvents immediately around the MAIN kernel of the next
+ * conv launches that match (kind, cin, cout, kh).  kind: 0 forward, 1 backward-data, 2 backward-weights.
+ * ev_start/ev_stop: host arrays of n hipEvent_t (created with timing enabled); launch i uses slot
+ * i % n.  n == 0 disarms.  Returns the number of matching launches recorded so far via zns_probe_count(). */
+int zns_probe_arm(int kind, int cin, int cout, int kh, void* const* ev_start, void* const* ev_stop, int n);
+int zns_probe_count(void);
+
 /* ------------------------------------------------------------------ conv layers
  * One call = one `nn.Conv2d` (+ the MaxPool2d/ReLU/Dropout that follow it) of
  * _CNN.forward, models.py:37-70, for `nbr` branches at once.

@@ -138,7 +138,7 @@ def test_pretext_step_golden(golden):
             np.testing.assert_allclose(a.detach().cpu().numpy(), g["s0_anc_emb"], atol=1e-4)
             np.testing.assert_allclose(p.detach().cpu().numpy(), g["s0_pos_emb"], atol=1e-4)
             for k, v in m.named_parameters():
-                check_stats(v.grad, g[f"s0_grad_{k}_stats"], g[f"s0_grad_{k}_samples"])
+                check_stats(v.grad, g[f"s0_grad_{k}_stats"], g[f"s0_grad_{k}_samples"], rtol=GRAD_RTOL, srtol=0.1)
         opt.step()
         if it in (0, 2):
             for k, v in m.named_parameters():
@@ -189,7 +189,7 @@ def test_finetune_step_golden(golden):
         assert abs(loss.item() - float(g[f"{red}_loss"])) < 2e-5
         np.testing.assert_allclose(o.detach().cpu().numpy(), g[f"{red}_out"], atol=1e-4)
         for k, v in d.named_parameters():
-            check_stats(v.grad, g[f"{red}_grad_{k}_stats"], g[f"{red}_grad_{k}_samples"])
+            check_stats(v.grad, g[f"{red}_grad_{k}_stats"], g[f"{red}_grad_{k}_samples"], rtol=GRAD_RTOL, srtol=0.1)
         opt.step()
         for k, v in d.named_parameters():
             check_stats(v, g[f"{red}_s0_param_{k}_stats"], g[f"{red}_s0_param_{k}_samples"], rtol=1e-5)

@@ -9,6 +9,7 @@ namespace zns {
 
 static thread_local char g_err[512] = "";
 static int g_impl = ZNS_IMPL_AUTO;
+Probe g_probe;
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -40,6 +41,19 @@ int zns_set_impl(int impl) {
     g_impl = impl;
     return prev;
 }
+
+int zns_probe_arm(int kind, int cin, int cout, int kh, void* const* ev_start, void* const* ev_stop, int n) {
+    delete[] g_probe.start;
+    delete[] g_probe.stop;
+    g_probe = Probe{};
+    if (n <= 0) return ZNS_OK;
+    g_probe.kind = kind; g_probe.cin = cin; g_probe.cout = cout; g_probe.kh = kh; g_probe.n = n;
+    g_probe.start = new hipEvent_t[n];
+    g_probe.stop = new hipEvent_t[n];
+    for (int i = 0; i < n; ++i) { g_probe.start[i] = (hipEvent_t)ev_start[i]; g_probe.stop[i] = (hipEvent_t)ev_stop[i]; }
+    return ZNS_OK;
+}
+int zns_probe_count(void) { return g_probe.count; }
 
 size_t zns_conv2d_workspace_bytes(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H) {
     ConvArgs a{nbr, B, T, cin, cout, kh, kw, H, 1};

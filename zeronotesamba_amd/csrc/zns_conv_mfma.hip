@@ -605,8 +605,12 @@ static int launch_core(const ConvArgs& a, CoreArgs A, Ptr2 w, int transposed, vo
     A.N = a.nbr * a.B;
     A.ncb = ceil_div(a.T, C::WB);
     const long long blocks = (long long)A.N * (C::H / C::RB) * A.ncb * (C::COUT / C::COB);
+    const bool probe = probe_match(transposed ? 1 : 0, a.cin, a.cout, a.kh);
+    const int slot = probe ? g_probe.count % g_probe.n : 0;
+    if (probe) ZNS_HIP(hipEventRecord(g_probe.start[slot], st));
     hipLaunchKernelGGL(conv_core<C>, dim3((unsigned)blocks), dim3(C::NT), C::LDS_BYTES, st, A);
     ZNS_LAUNCH_CHECK();
+    if (probe) { ZNS_HIP(hipEventRecord(g_probe.stop[slot], st)); ++g_probe.count; }
     return ZNS_OK;
 }
 
@@ -673,8 +677,12 @@ static int launch_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr
     int rc = set_lds_wg<C>(wgrad_core<C>);
     if (rc) return rc;
     const long long blocks = (long long)C::NQG * (C::CIN / 32) * (C::COUT / C::COB) * A.KS * a.nbr;
+    const bool probe = probe_match(2, a.cin, a.cout, a.kh);
+    const int slot = probe ? g_probe.count % g_probe.n : 0;
+    if (probe) ZNS_HIP(hipEventRecord(g_probe.start[slot], st));
     hipLaunchKernelGGL(wgrad_core<C>, dim3((unsigned)blocks), dim3(C::NT), C::LDS_BYTES, st, A);
     ZNS_LAUNCH_CHECK();
+    if (probe) { ZNS_HIP(hipEventRecord(g_probe.stop[slot], st)); ++g_probe.count; }
     const long long total = (long long)a.nbr * C::Q * C::COUT * C::CIN;
     const int rblocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rblocks), dim3(256), 0, st, (const float*)ws, dw, A.KS, C::Q, C::COUT,

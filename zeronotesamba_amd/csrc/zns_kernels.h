@@ -4,6 +4,17 @@
 
 namespace zns {
 
+// bench.py measurement hook (zns_probe_arm): events around the main kernel of matching launches
+struct Probe {
+    int kind = -1, cin = 0, cout = 0, kh = 0, n = 0, count = 0;
+    hipEvent_t* start = nullptr;
+    hipEvent_t* stop = nullptr;
+};
+extern Probe g_probe;
+inline bool probe_match(int kind, int cin, int cout, int kh) {
+    return g_probe.n > 0 && g_probe.kind == kind && g_probe.cin == cin && g_probe.cout == cout && g_probe.kh == kh;
+}
+
 struct ConvArgs {
     int nbr, B, T, cin, cout, kh, kw, H, pool;
 };

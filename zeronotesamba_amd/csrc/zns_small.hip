@@ -220,8 +220,8 @@ __global__ void __launch_bounds__(1024) bce_kernel(const float* __restrict__ o, 
 // ------------------------------------------------------------------ Adam (torch.optim.Adam defaults)
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, size_t n, float b1, float b2, float eps, float step_size,
-                            float sqrt_bc2, float grad_scale) {
-    const size_t n4 = n / 4;
+                            float sqrt_bc2, float grad_scale, int aligned) {
+    const size_t n4 = aligned ? n / 4 : 0;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
@@ -345,17 +345,16 @@ int zns_bce_f32(const float* out, const float* target, size_t n, float* loss, fl
 int zns_adam_step_f32(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                       float eps, int step, float grad_scale, void* stream) {
     ZNS_CHECK_ARG(step >= 1, "adam: step must be >= 1");
-    ZNS_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0,
-                  "adam: buffers must be 16-byte aligned");
+    const int aligned = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
     if (n == 0) return ZNS_OK;
     const double bc1 = 1.0 - pow((double)beta1, step);
     const double bc2 = 1.0 - pow((double)beta2, step);
     const float step_size = (float)((double)lr / bc1);
     const float sqrt_bc2 = (float)sqrt(bc2);
-    const size_t want = (n / 4 + 255) / 256;
+    const size_t want = ((aligned ? n / 4 : n) + 255) / 256;
     const int blocks = (int)(want > 4096 ? 4096 : (want ? want : 1));
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, beta1, beta2, eps,
-                       step_size, sqrt_bc2, grad_scale);
+                       step_size, sqrt_bc2, grad_scale, aligned);
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
 }
