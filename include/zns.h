@@ -133,6 +133,9 @@ int zns_adam_step_f32(float* p, const float* g, float* m, float* v, size_t n,
  * The filter bank (host, float64) is built once per (mode) and cached on the device. */
 size_t zns_xqt_workspace_bytes(int n_clips, int n_samples, int mode);
 int zns_xqt_frames(int n_samples);
+/* HOST-only helper (no GPU touched): the folded per-octave FIR bank the kernel applies, as interleaved
+ * re/im floats [octave][12][n_fft[octave]], and the 32+31 decimation taps.  Used by the CPU tests. */
+int zns_xqt_host_bank(int mode, int* n_fft8, float* fir, size_t fir_floats, double* taps63);
 int zns_xqt_f32(const float* wav, int n_clips, int n_samples, int sample_rate, int mode,
                 float* out, void* ws, size_t ws_bytes, void* stream);
 

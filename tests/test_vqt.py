@@ -1,0 +1,132 @@
+"""generate_XQT: the oracle's known-answer checks (CPU) and HIP-vs-oracle parity (GPU).
+
+The oracle for this function is PARITY UNPINNED (librosa 0.8.1 / resampy 0.4.2 absent, oracle/vqt_ref.py);
+what is pinned here without them: output shape and dtype (pretext.py:255,285 hard-code 626 / 313 frames),
+a bin-centred sinusoid's peak bin and magnitude (A/2)*sqrt(Q*sr/(f+gamma/alpha)), linearity, the silence
+floor log(1e-9), CQT == VQT with gamma = 0, and that the C++ filter bank equals the numpy one."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vqt_ref
+
+
+def noise(seed, n, sigma=0.1):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / 16000.0
+    chirp = 0.05 * np.sin(2 * np.pi * (200.0 * t + 0.5 * 300.0 * t * t))
+    return (sigma * rng.standard_normal(n) + chirp).astype(np.float32)
+
+
+# ------------------------------------------------------------------ CPU: oracle known answers
+def test_oracle_shapes_and_floor():
+    for n, T in ((160000, 626), (80000, 313), (131000, 512), (20001, 79)):
+        X = vqt_ref.generate_XQT(noise(1, n), 16000, "vqt")
+        assert X.shape == (96, T) and X.dtype == np.float32
+    Z = vqt_ref.generate_XQT(np.zeros(20000, dtype=np.float32), 16000, "vqt")
+    np.testing.assert_allclose(Z, np.log(1e-9), atol=1e-6)   # silence -> log(eps) = -20.7233
+    with pytest.raises(Exception, match="Mode can only be vqt or cqt!"):
+        vqt_ref.generate_XQT(noise(1, 20000), 16000, "stft")
+
+
+@pytest.mark.parametrize("mode", ["vqt", "cqt"])
+@pytest.mark.parametrize("k", [30, 60, 90])
+def test_oracle_sinusoid_known_answer(mode, k):
+    f = vqt_ref.FMIN * 2 ** (k / 12)
+    A = 0.5
+    s = (A * np.sin(2 * np.pi * f * np.arange(64000) / 16000)).astype(np.float32)
+    X = np.exp(vqt_ref.generate_XQT(s, 16000, mode))
+    col = X[:, 120]
+    a = vqt_ref.alpha()
+    pred = (A / 2) * np.sqrt((1 / a) * 16000 / (f + vqt_ref.gamma_for(mode) / a))
+    assert col.argmax() == k
+    assert abs(col.max() - pred) / pred < 0.01
+
+
+def test_oracle_linearity_and_fir_equivalence():
+    y = noise(3, 40000)
+    V1 = vqt_ref.xqt_complex(y, "vqt")
+    V2 = vqt_ref.xqt_complex((2.0 * y).astype(np.float32), "vqt")
+    np.testing.assert_allclose(V2, 2 * V1, rtol=0, atol=2e-5 * np.abs(V1).max())
+    Vt = vqt_ref.xqt_time_domain(y, "vqt")
+    np.testing.assert_allclose(Vt, V1, rtol=0, atol=2e-6 * np.abs(V1).max())
+
+
+def test_host_filter_bank_matches_oracle():
+    from zeronotesamba_amd import _lib
+    L = _lib.lib()
+    for mode, mid in (("vqt", 0), ("cqt", 1)):
+        nfft = (C.c_int * 8)()
+        assert L.zns_xqt_host_bank(mid, nfft, None, 0, None) == 0
+        nf = list(nfft)
+        bank, _ = vqt_ref.filter_bank(mode)
+        assert nf == [o["n_fft"] for o in bank]
+        tot = sum(12 * n * 2 for n in nf)
+        fir = (C.c_float * tot)()
+        taps = (C.c_double * 63)()
+        assert L.zns_xqt_host_bank(mid, nfft, fir, tot, taps) == 0
+        fir = np.frombuffer(fir, dtype=np.float32)
+        o = 0
+        for i, g_ref in enumerate(vqt_ref.time_domain_bank(mode)):
+            g = fir[o:o + 12 * nf[i] * 2].reshape(12, nf[i], 2)
+            o += 12 * nf[i] * 2
+            np.testing.assert_allclose(g[..., 0] + 1j * g[..., 1], g_ref, rtol=0, atol=2e-7 * np.abs(g_ref).max())
+        left, right = vqt_ref.decimate2_taps()
+        t = np.frombuffer(taps, dtype=np.float64)
+        np.testing.assert_allclose(t[:32], left, rtol=1e-13, atol=1e-16)
+        np.testing.assert_allclose(t[32:], right, rtol=1e-13, atol=1e-16)
+
+
+# ------------------------------------------------------------------ GPU: kernel vs oracle
+def lin_err(got_log, ref_log):
+    """Compare in the linear domain relative to the loudest bin: log() amplifies fp32 noise in near-silent bins."""
+    g, r = np.exp(got_log.astype(np.float64)), np.exp(ref_log.astype(np.float64))
+    return np.abs(g - r).max() / r.max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["vqt", "cqt"])
+@pytest.mark.parametrize("n", [160000, 80000, 33333, 4097])
+def test_generate_xqt_matches_oracle(mode, n):
+    from zeronotesamba_amd.processing.input_rep import generate_XQT
+    y = noise(10 + n % 7, n)
+    got = generate_XQT(y, 16000, mode)
+    ref = vqt_ref.generate_XQT(y, 16000, mode)
+    assert got.shape == ref.shape == (96, 1 + n // 256) and got.dtype == np.float32
+    assert lin_err(got, ref) < 1e-5
+    # broadband input: every bin is far above the 1e-9 floor, so the log outputs agree to 1e-4 as well
+    assert np.abs(got - ref).max() < 1e-4
+
+
+@pytest.mark.gpu
+def test_generate_xqt_batch_and_errors():
+    from zeronotesamba_amd.processing.input_rep import generate_XQT, generate_XQT_batch
+    ys = np.stack([noise(20 + i, 40000) for i in range(5)])
+    out = generate_XQT_batch(torch.from_numpy(ys).cuda(), 16000, "vqt").cpu().numpy()
+    for i in range(5):
+        assert lin_err(out[i], vqt_ref.generate_XQT(ys[i], 16000, "vqt")) < 1e-5
+    z = generate_XQT(np.zeros(30000, dtype=np.float32), 16000, "vqt")
+    np.testing.assert_allclose(z, np.log(1e-9), atol=1e-5)
+    with pytest.raises(Exception, match="Mode can only be vqt or cqt!"):
+        generate_XQT(ys[0], 16000, "mel")
+    with pytest.raises(RuntimeError, match="16000"):
+        generate_XQT(ys[0], 22050, "vqt")
+    with pytest.raises(RuntimeError, match="too short"):
+        generate_XQT(ys[0][:1000], 16000, "vqt")
+    with pytest.raises(ValueError):
+        generate_XQT(ys, 16000, "vqt")
+
+
+@pytest.mark.gpu
+def test_generate_xqt_linearity_at_full_size():
+    """Size-independent property at BASELINE config 2 size: 32 clips x 160 000 samples."""
+    from zeronotesamba_amd.processing.input_rep import generate_XQT_batch
+    g = torch.Generator().manual_seed(1234)
+    y = (0.1 * torch.randn(32, 160000, generator=g)).cuda()
+    a = generate_XQT_batch(y, 16000, "vqt")
+    b = generate_XQT_batch(2.0 * y, 16000, "vqt")
+    assert tuple(a.shape) == (32, 96, 626)
+    # V(2y) = 2 V(y)  ->  log|V| shifts by log 2
+    assert (b - a - np.log(2.0)).abs().max().item() < 2e-4
