@@ -314,17 +314,18 @@ struct WgCfg {
     static constexpr int NW = WMW * WQ, NT = NW * 64;
     static constexpr int COB = WMW * MT * 32;
     static constexpr int G = WQ * NS, Q = KH * KW, NQG = (Q + G - 1) / G;
-    static constexpr int CW = 64;
+    static constexpr int CW = 64;                            // pixels per K-tile: one image row segment
     static constexpr int PH = KH / 2, PW = KW / 2;
-    static constexpr int RSPAN = (KW - 1 + G - 1) / KW + 1;
-    static constexpr int PRW = R + RSPAN - 1, PCW = CW + KW - 1;
-    static constexpr int PS = (PRW * PCW) | 1;
-    static constexpr int ZS = (R * CW) | 1;
-    static constexpr int ZBUF = ((COB * ZS + 63) / 64) * 64;
+    static constexpr int RSPAN = (KW - 1 + G - 1) / KW + 1;  // distinct kernel rows a workgroup's shift range touches
+    static constexpr int PRW = RSPAN, PCW = CW + KW - 1;
+    static constexpr int PS = (PRW * PCW) | 1;               // odd plane stride: lanes (= channels) hit distinct banks
+    static constexpr int ZBUF = COB * CW;                    // dZ tile [COB][64], 16-byte chunks XOR-swizzled by co&15
     static constexpr int XBUF = ((32 * PS + 63) / 64) * 64;
+    static constexpr int NXI = (XBUF / 64 + NW - 1) / NW;    // X-patch DMA instructions per wave
     static constexpr int LDS_BYTES = 2 * (ZBUF + XBUF) * 4;
-    static_assert(CIN % 32 == 0 && COUT % COB == 0 && H % R == 0, "tiling");
-    static_assert(MT * NS * 16 <= 160, "accumulator budget");
+    static_assert(R == 1, "one image row per K-tile");
+    static_assert(CIN % 32 == 0 && COUT % COB == 0, "tiling");
+    static_assert(COB % 4 == 0 && MT * NS * 16 <= 160, "accumulator budget");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
@@ -336,36 +337,52 @@ struct WgArgs {
     int KS, tiles_per_split, tiles_total;   // per branch
 };
 
+// Stage one K-tile (image row h0, columns w0..w0+63 of sample n):
+//   dZ  [COB][64]            16-byte chunk c of channel co is stored at chunk position c ^ (co & 15)
+//   X   [32][PRW][PCW] (+pad) rows h0+r0-PH .., columns w0-PW .., zero outside the image
+// xrel / xrc: per-lane source offsets of this wave's X-patch DMA instructions, computed once per kernel.
 template <class C>
 __device__ __forceinline__ void wg_load_tile(const WgArgs& A, int br, int cob, int cit, int r0, int tile, float* zb,
-                                             float* xb, int wid, int lane) {
+                                             float* xb, int wid, int lane, const int (&xrel)[C::NXI],
+                                             const int (&xrc)[C::NXI]) {
     const int T = A.T;
     const int cbk = tile % A.ncb;
-    const int rbk = (tile / A.ncb) % (C::H / C::R);
-    const int b = tile / (A.ncb * (C::H / C::R));
+    const int h0 = (tile / A.ncb) % C::H;
+    const int b = tile / (A.ncb * C::H);
     const int n = br * A.B + b;
-    const int h0 = rbk * C::R, w0 = cbk * C::CW;
-    // dZ tile: one 64-float row segment per DMA instruction, rows of a channel ZS apart (odd stride)
-    const float* zn = A.dz + ((size_t)n * C::COUT + (size_t)cob * C::COB) * C::H * T;
-    for (int q = wid; q < C::COB * C::R; q += C::NW) {
-        const int co = q / C::R, row = q - co * C::R;
-        const int ww = w0 + lane;
-        const float* src = (ww < T) ? zn + ((size_t)co * C::H + h0 + row) * T + ww : g_zero_page;
-        glds4(src, zb + co * C::ZS + row * C::CW);
+    const int w0 = cbk * C::CW;
+    const float* zrow = A.dz + (((size_t)n * C::COUT + (size_t)cob * C::COB) * C::H + h0) * T + w0;
+    const size_t zplane = (size_t)C::H * T;
+    const bool fastz = ((T & 3) == 0) && (w0 + C::CW <= T) && ((reinterpret_cast<uintptr_t>(A.dz) & 15) == 0);
+    if (fastz) {
+        // 16 lanes x 16 B = one row segment; one DMA instruction stages 4 channels (1 KiB, LDS-linear)
+        for (int q = wid; q < C::COB / 4; q += C::NW) {
+            const int co = 4 * q + (lane >> 4);
+            const int c = (lane & 15) ^ (co & 15);
+            glds16(zrow + (size_t)co * zplane + c * 4, zb + q * 256);
+        }
+    } else {
+        for (int q = wid; q < C::COB; q += C::NW) {
+            const int col = (((lane >> 2) ^ (q & 15)) << 2) + (lane & 3);
+            const float* src = (w0 + col < T) ? zrow + (size_t)q * zplane + col : g_zero_page;
+            glds4(src, zb + q * C::CW);
+        }
     }
-    // X patch for 32 input channels
-    const float* xn = A.x + ((size_t)n * C::CIN + (size_t)cit * 32) * C::H * T;
-    constexpr int NI = C::XBUF / 64;
-    for (int q = wid; q < NI; q += C::NW) {
-        const int L = q * 64 + lane;
-        const int ci = L / C::PS;
-        const int rem = L - ci * C::PS;
-        const int row = rem / C::PCW;
-        const int col = rem - row * C::PCW;
-        const int hh = h0 + r0 - C::PH + row, ww = w0 - C::PW + col;
-        const bool ok = (ci < 32) && (row < C::PRW) && hh >= 0 && hh < C::H && ww >= 0 && ww < T;
-        const float* src = ok ? xn + ((size_t)ci * C::H + hh) * T + ww : g_zero_page;
-        glds4(src, xb + q * 64);
+    const int hbase = h0 + r0 - C::PH, wbase = w0 - C::PW;
+    const bool interior = hbase >= 0 && hbase + C::PRW <= C::H && wbase >= 0 && wbase + C::PCW <= T;
+    const float* xbase = A.x + ((size_t)n * C::CIN + (size_t)cit * 32) * C::H * T + (ptrdiff_t)hbase * T + wbase;
+#pragma unroll
+    for (int i = 0; i < C::NXI; ++i) {
+        const int q = wid + i * C::NW;
+        if (q < C::XBUF / 64) {
+            bool ok = xrel[i] >= 0;
+            if (!interior) {
+                const int hh = hbase + (xrc[i] >> 16), ww = wbase + (xrc[i] & 0xffff);
+                ok = ok && (unsigned)hh < (unsigned)C::H && (unsigned)ww < (unsigned)T;
+            }
+            const float* src = ok ? xbase + xrel[i] : g_zero_page;
+            glds4(src, xb + q * 64);
+        }
     }
 }
 
@@ -401,39 +418,58 @@ __global__ void __launch_bounds__(C::NT) wgrad_core(WgArgs A) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[m][s][k] = 0.f;
 
-    // per-lane LDS bases
-    const int zbase = ((wmw * C::MT) * 32 + lane_j) * C::ZS + lane_h;
+    // X-patch DMA source offsets of this wave (tile independent)
+    int xrel[C::NXI], xrc[C::NXI];
+#pragma unroll
+    for (int i = 0; i < C::NXI; ++i) {
+        const int L = (wid + i * C::NW) * 64 + lane;
+        const int ci = L / C::PS;
+        const int rem = L - ci * C::PS;
+        const int row = rem / C::PCW;
+        const int col = rem - row * C::PCW;
+        const bool ok = ci < 32 && row < C::PRW;
+        xrel[i] = ok ? (ci * C::H + row) * A.T + col : -1;
+        xrc[i] = (row << 16) | col;
+    }
+
+    // per-lane LDS read bases.  A (dZ): channel = lane_j, 4 consecutive pixels per ds_read_b128; the k index of MFMA s
+    // in pixel group g is pixel 8g + 4*lane_h + s for BOTH operands.
+    const int zrowbase = ((wmw * C::MT) * 32 + lane_j) * C::CW;
+    const int zswz = lane_h ^ (lane_j & 15);
     int xoff[C::NS];
 #pragma unroll
     for (int s = 0; s < C::NS; ++s) {
         int q = q0 + wq * C::NS + s;
         if (q >= C::Q) q = C::Q - 1;   // padded shift: computed, never stored
         const int rr = q / C::KW, ss = q - rr * C::KW;
-        xoff[s] = lane_j * C::PS + (rr - r0) * C::PCW + ss + lane_h;
+        xoff[s] = lane_j * C::PS + (rr - r0) * C::PCW + ss + 4 * lane_h;
     }
 
-    if (t_begin < t_end) wg_load_tile<C>(A, br, cob, cit, r0, t_begin, zbuf(0), xbuf(0), wid, lane);
+    if (t_begin < t_end) wg_load_tile<C>(A, br, cob, cit, r0, t_begin, zbuf(0), xbuf(0), wid, lane, xrel, xrc);
     int cur = 0;
     for (int tile = t_begin; tile < t_end; ++tile, cur ^= 1) {
         wait_vm0();
         __syncthreads();
-        if (tile + 1 < t_end) wg_load_tile<C>(A, br, cob, cit, r0, tile + 1, zbuf(cur ^ 1), xbuf(cur ^ 1), wid, lane);
-        const float* __restrict__ zp = zbuf(cur) + zbase;
+        if (tile + 1 < t_end)
+            wg_load_tile<C>(A, br, cob, cit, r0, tile + 1, zbuf(cur ^ 1), xbuf(cur ^ 1), wid, lane, xrel, xrc);
+        const float* __restrict__ zp = zbuf(cur) + zrowbase;
         const float* __restrict__ xp = xbuf(cur);
 #pragma unroll
-        for (int prow = 0; prow < C::R; ++prow) {
+        for (int g = 0; g < C::CW / 8; ++g) {
+            f32x4 a4[C::MT];
+            const int chunk = (2 * g) ^ zswz;
 #pragma unroll
-            for (int pc = 0; pc < C::CW / 2; ++pc) {
-                float a[C::MT], b[C::NS];
+            for (int m = 0; m < C::MT; ++m) a4[m] = *reinterpret_cast<const f32x4*>(zp + m * 32 * C::CW + chunk * 4);
 #pragma unroll
-                for (int m = 0; m < C::MT; ++m) a[m] = zp[m * 32 * C::ZS + prow * C::CW + 2 * pc];
+            for (int s4 = 0; s4 < 4; ++s4) {
+                float b[C::NS];
 #pragma unroll
-                for (int s = 0; s < C::NS; ++s) b[s] = xp[xoff[s] + prow * C::PCW + 2 * pc];
+                for (int s = 0; s < C::NS; ++s) b[s] = xp[xoff[s] + 8 * g + s4];
 #pragma unroll
                 for (int m = 0; m < C::MT; ++m)
 #pragma unroll
                     for (int s = 0; s < C::NS; ++s)
-                        acc[m][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[s], acc[m][s], 0, 0, 0);
+                        acc[m][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[m][s4], b[s], acc[m][s], 0, 0, 0);
             }
         }
     }
@@ -516,19 +552,48 @@ static int layer_of(const ConvArgs& a) {
 
 bool mfma_supported(const ConvArgs& a) { return layer_of(a) > 0 && a.nbr >= 1 && a.nbr <= 2; }
 
+static int device_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            cus = n;
+        else
+            cus = 256;   // MI355X; also the answer when no device is visible (workspace queries on a CPU box)
+    }
+    return cus;
+}
+
+// Split-K factor for backward-weights.  One workgroup per CU is resident (LDS), every workgroup does the same
+// work, so the launch runs in ceil(WGs / CUs) rounds: pick KS that wastes the least of the last round and of the
+// last (ragged) split, among launches of >= 2 rounds' worth of workgroups, preferring the smaller slab on ties.
 template <class C>
 static int wg_pick_ks(const ConvArgs& a, int* tiles_total, int* tps) {
     const int ncb = ceil_div(a.T, C::CW);
-    const int total = a.B * (C::H / C::R) * ncb;
+    const int total = a.B * C::H * ncb;
     const int base = C::NQG * (C::CIN / 32) * (C::COUT / C::COB) * a.nbr;
-    int ks = ceil_div(1024, base);
-    if (ks > total) ks = total;
-    if (ks < 1) ks = 1;
-    const int per = ceil_div(total, ks);
-    ks = ceil_div(total, per);
+    const int cus = device_cus();
+    int best_ks = 1;
+    double best_eff = -1.0;
+    const int ks_max = total < 256 ? total : 256;
+    for (int ks = 1; ks <= ks_max; ++ks) {
+        const int per = ceil_div(total, ks);
+        if (ceil_div(total, per) != ks) continue;              // not a distinct split
+        const long long wgs = (long long)base * ks;
+        const long long rounds = (wgs + cus - 1) / cus;
+        double eff = (double)wgs / (double)(rounds * cus) * ((double)total / ((double)ks * per));
+        if (wgs < cus) eff *= 0.5;                               // do not leave CUs without a workgroup
+        if (eff > best_eff + 0.02 || (eff > best_eff - 1e-9 && wgs >= 2LL * cus && (long long)base * best_ks < 2LL * cus)) {
+            best_eff = eff;
+            best_ks = ks;
+        }
+        if (best_eff > 0.985 && (long long)base * best_ks >= 2LL * cus) break;
+    }
+    const int per = ceil_div(total, best_ks);
     *tiles_total = total;
     *tps = per;
-    return ks;
+    return ceil_div(total, per);
 }
 
 template <class C>
