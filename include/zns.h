@@ -35,8 +35,9 @@ extern "C" {
 #define ZNS_ERR_WORKSPACE (-2)   /* workspace too small */
 #define ZNS_ERR_MODE (-3)        /* generate_XQT: "Mode can only be vqt or cqt!" (input_rep.py:56-57) */
 
-#define ZNS_IMPL_AUTO 0          /* MFMA / tuned kernels */
+#define ZNS_IMPL_AUTO 0          /* fastest kernels: frequency-domain MFMA path where it applies, else direct MFMA */
 #define ZNS_IMPL_NAIVE 1         /* one-thread-per-output HIP kernels, for on-device validation only */
+#define ZNS_IMPL_DIRECT 2        /* direct (time-domain) implicit-GEMM MFMA kernels only */
 
 #define ZNS_REDUCE_MAX 0         /* Down_CNN(reduction="max"), models.py:147-148 */
 #define ZNS_REDUCE_MEAN 1        /* Down_CNN(reduction="mean"), models.py:144-145 */

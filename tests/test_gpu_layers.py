@@ -30,7 +30,7 @@ def close(got: torch.Tensor, ref: torch.Tensor, tol=1e-4, what=""):
     assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
 
 
-CASES = [(li, impl) for li in range(8) for impl in ("naive", "mfma")]
+CASES = [(li, impl) for li in range(8) for impl in ("naive", "direct", "auto")]   # auto = frequency-domain path on cv2..cv6
 
 
 @pytest.mark.parametrize("li,impl", CASES)
@@ -63,7 +63,7 @@ def test_conv_layer(li, impl, T):
         ams.append(am)
     y_ref = torch.cat(ys).detach()
 
-    prev = L.zns_set_impl(_lib.ZNS_IMPL_NAIVE if impl == "naive" else _lib.ZNS_IMPL_AUTO)
+    prev = L.zns_set_impl({"naive": _lib.ZNS_IMPL_NAIVE, "direct": _lib.ZNS_IMPL_DIRECT, "auto": _lib.ZNS_IMPL_AUTO}[impl])
     try:
         xd = x.to(dev)
         wd = [t.to(dev) for t in w]

@@ -46,7 +46,7 @@ SIGNATURES = {
     "zns_shift_gather_f32": (C.c_int, [c_fp, C.c_int, c_fp, c_fp, C.c_int, C.c_int, c_fp, c_fp]),
 }
 
-ZNS_IMPL_AUTO, ZNS_IMPL_NAIVE = 0, 1
+ZNS_IMPL_AUTO, ZNS_IMPL_NAIVE, ZNS_IMPL_DIRECT = 0, 1, 2
 ZNS_REDUCE_MAX, ZNS_REDUCE_MEAN = 0, 1
 ZNS_MODE_VQT, ZNS_MODE_CQT = 0, 1
 ZNS_ERR_MODE = -3

@@ -60,6 +60,7 @@ size_t zns_conv2d_workspace_bytes(int nbr, int B, int T, int cin, int cout, int 
     size_t n = 256;
     if (is_cv1(a)) n = cv1_workspace_bytes(a);
     else if (mfma_supported(a)) n = mfma_workspace_bytes(a);
+    if (fft_supported(a) && fft_workspace_bytes(a) > n) n = fft_workspace_bytes(a);
     return (n + 255) & ~(size_t)255;
 }
 
@@ -75,6 +76,8 @@ int zns_conv2d_fwd_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw,
     hipStream_t st = (hipStream_t)stream;
     if (g_impl == ZNS_IMPL_NAIVE) return naive_fwd(a, x, pw, pb, y, argmax, drop_p, seed, layer, st);
     if (is_cv1(a) && pool == 1) return cv1_fwd(a, x, pw, pb, y, drop_p, seed, layer, st);
+    if (g_impl == ZNS_IMPL_AUTO && fft_supported(a))
+        return fft_fwd(a, x, pw, pb, y, argmax, drop_p, seed, layer, ws, ws_bytes, st);
     if (mfma_supported(a)) return mfma_fwd(a, x, pw, pb, y, argmax, drop_p, seed, layer, ws, ws_bytes, st);
     set_error("conv2d_fwd: no gfx950 kernel instance for cin=%d cout=%d k=%dx%d H=%d", cin, cout, kh, kw, H);
     return ZNS_ERR_ARG;
@@ -91,6 +94,8 @@ int zns_conv2d_dgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int k
     for (int i = 0; i < nbr; ++i) pw.p[i] = w[i];
     hipStream_t st = (hipStream_t)stream;
     if (g_impl == ZNS_IMPL_NAIVE) return naive_dgrad(a, dz, pw, dx, x, inv_keep, prev_argmax, prev_pool, st);
+    if (g_impl == ZNS_IMPL_AUTO && fft_supported(a))
+        return fft_dgrad(a, dz, pw, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
     if (mfma_supported(a)) return mfma_dgrad(a, dz, pw, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
     set_error("conv2d_dgrad: no gfx950 kernel instance for cin=%d cout=%d k=%dx%d H=%d", cin, cout, kh, kw, H);
     return ZNS_ERR_ARG;
@@ -112,7 +117,8 @@ int zns_conv2d_wgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int k
     }
     if (is_cv1(a)) return cv1_wgrad(a, dz, x, pdw, pdb, accumulate, ws, ws_bytes, st);
     if (mfma_supported(a)) {
-        rc = mfma_wgrad(a, dz, x, pdw, accumulate, ws, ws_bytes, st);
+        rc = (g_impl == ZNS_IMPL_AUTO && fft_supported(a)) ? fft_wgrad(a, dz, x, pdw, accumulate, ws, ws_bytes, st)
+                                                           : mfma_wgrad(a, dz, x, pdw, accumulate, ws, ws_bytes, st);
         if (rc) return rc;
         return channel_sum(nbr, B, cout, (long long)H * T, dz, pdb, accumulate, st);
     }

@@ -1,0 +1,558 @@
+// Templates of the two fp32-MFMA convolution cores (conv_core: forward / backward-data, wgrad_core:
+// backward-weights) shared by the direct path (zns_conv_mfma.hip) and the frequency-domain path
+// (zns_conv_fft.hip).  See zns_conv_mfma.hip for the design notes.
+#pragma once
+#include "zns_common.h"
+#include "zns_kernels.h"
+
+namespace zns {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+static __device__ const float g_zero_page[16] = {0};
+
+__device__ __forceinline__ void glds4(const float* src, float* lds_dst) {
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)lds_dst, 4, 0, 0);
+}
+__device__ __forceinline__ void glds16(const float* src, float* lds_dst) {
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)lds_dst, 16, 0, 0);
+}
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// MFMA 32x32 accumulator: lane&31 = column, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+__device__ __forceinline__ int acc_row(int reg, int lane_h) { return (reg & 3) + 8 * (reg >> 2) + 4 * lane_h; }
+
+// =====================================================================================================
+//                                   forward / backward-data core
+// =====================================================================================================
+// DILMAX > 0 selects the frequency-domain use of the core (see zns_conv_fft.hip): a 1-D correlation with KW taps
+// spaced `dil` (runtime, <= DILMAX) apart along the flattened (row, time-block) axis, weights chosen per frequency.
+template <int CIN_, int COUT_, int KH_, int KW_, int H_, int MT_, int RT_, int CT_, int WM_, int WR_, int WC_,
+          int CK_, int POOL_, int EPI_, int DILMAX_ = 0>
+struct ConvCfg {
+    static constexpr int DILMAX = DILMAX_;
+    static constexpr int CIN = CIN_, COUT = COUT_, KH = KH_, KW = KW_, H = H_;
+    static constexpr int MT = MT_, RT = RT_, CT = CT_, WM = WM_, WR = WR_, WC = WC_, CK = CK_;
+    static constexpr int POOL = POOL_, EPI = EPI_;
+    static constexpr int NW = WM * WR * WC, NT = NW * 64;
+    static constexpr int COB = WM * MT * 32, RB = WR * RT, WB = WC * CT * 32;
+    static constexpr int PH = KH / 2, PW = KW / 2;
+    static constexpr int PR = RB + KH - 1, PCW = WB + (KW - 1) * (DILMAX ? DILMAX : 1);
+    static constexpr int PS = (PR * PCW) | 1;                 // odd plane stride
+    static constexpr int PATCH = ((CK * PS + 63) / 64) * 64;  // floats per patch buffer
+    static constexpr int SLAB = CK * KW * COB;                // floats per weight stage
+    static constexpr int NCC = CIN / CK, NST = NCC * KH;
+    static constexpr int LDS_BYTES = (2 * SLAB + 2 * PATCH) * 4;
+    static constexpr int HP = H / POOL;
+    static_assert(CIN % CK == 0 && CK % 2 == 0, "CK");
+    static_assert(COUT % COB == 0, "COB");
+    static_assert(H % RB == 0, "RB");
+    static_assert(SLAB % 256 == 0, "slab must be whole 1-KiB DMA pieces");
+    static_assert(RT % POOL == 0, "pool must divide the row tiles of a wave");
+    static_assert(MT == 1 || MT == 2 || MT == 4, "MT");
+    static_assert(MT * RT * CT * 16 <= 160, "accumulator budget");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+    static_assert(CK * PS * 4 < 65536, "ds_read immediate range");
+};
+
+struct CoreArgs {
+    const float* x;        // [N, CIN, H, T]
+    const float* wpk;      // packed weights, branch stride = COUT*CIN*KH*KW
+    int B, T, N;           // N = nbr*B (x F in the frequency-domain use)
+    int ncb;               // column blocks
+    int dil, F;            // DILMAX > 0 only: tap spacing, number of frequency slots (weights indexed by (branch, f))
+    // EPI 0
+    Ptr2 bias;
+    float* y;
+    uint8_t* argmax;
+    uint32_t thresh;
+    float inv_keep;
+    uint32_t seed;
+    int layer;
+    // EPI 1
+    float* dx;
+    const float* xmask;
+    const uint8_t* prev_argmax;
+    int prev_pool;
+};
+
+template <class C>
+__device__ __forceinline__ void load_patch(const float* xn, int cc, int h0, int w0, int T, float* lds_patch, int wid,
+                                           int lane, int pw = C::PW) {
+    constexpr int NI = C::PATCH / 64;
+    for (int q = wid; q < NI; q += C::NW) {
+        const int L = q * 64 + lane;
+        const int ci = L / C::PS;
+        const int rem = L - ci * C::PS;
+        const int row = rem / C::PCW;
+        const int col = rem - row * C::PCW;
+        const int hh = h0 - C::PH + row, ww = w0 - pw + col;
+        const bool ok = (ci < C::CK) && (row < C::PR) && hh >= 0 && hh < C::H && ww >= 0 && ww < T;
+        const float* src = ok ? xn + ((size_t)(cc * C::CK + ci) * C::H + hh) * T + ww : g_zero_page;
+        glds4(src, lds_patch + q * 64);
+    }
+}
+
+template <class C>
+__device__ __forceinline__ void load_slab(const float* wslab, float* lds_slab, int wid, int lane) {
+    constexpr int NI = C::SLAB / 256;
+    for (int q = wid; q < NI; q += C::NW) glds16(wslab + q * 256 + lane * 4, lds_slab + q * 256);
+}
+
+template <class C>
+__device__ __forceinline__ void compute_stage(const float* __restrict__ pa, const float* __restrict__ pb,
+                                              f32x16 (&acc)[C::MT][C::RT][C::CT], int dil = 1) {
+#pragma unroll
+    for (int cp = 0; cp < C::CK / 2; ++cp) {
+#pragma unroll
+        for (int s = 0; s < C::KW; ++s) {
+            float a[C::MT];
+            const float* ap = pa + (cp * C::KW + s) * (C::WM * 64 * C::MT);
+            if constexpr (C::MT == 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ap);
+                a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
+            } else if constexpr (C::MT == 2) {
+                const f32x2 v = *reinterpret_cast<const f32x2*>(ap);
+                a[0] = v[0]; a[1] = v[1];
+            } else {
+                a[0] = *ap;
+            }
+            float b[C::RT][C::CT];
+#pragma unroll
+            for (int rt = 0; rt < C::RT; ++rt)
+#pragma unroll
+                for (int ct = 0; ct < C::CT; ++ct)
+                    b[rt][ct] = pb[2 * cp * C::PS + rt * C::PCW + ct * 32 + (C::DILMAX ? s * dil : s)];
+#pragma unroll
+            for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+                for (int rt = 0; rt < C::RT; ++rt)
+#pragma unroll
+                    for (int ct = 0; ct < C::CT; ++ct)
+                        acc[m][rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[rt][ct], acc[m][rt][ct], 0, 0, 0);
+        }
+    }
+}
+
+template <class C>
+__global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    auto slab = [&](int i) -> float* { return smem + (i & 1) * C::SLAB; };
+    auto patch = [&](int i) -> float* { return smem + 2 * C::SLAB + (i & 1) * C::PATCH; };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane_j = lane & 31, lane_h = lane >> 5;
+    const int wc = wid % C::WC, wr = (wid / C::WC) % C::WR, wm = wid / (C::WC * C::WR);
+
+    // block -> (column block, row block, co block, sample)
+    int bid = blockIdx.x;
+    const int cb = bid % A.ncb;
+    bid /= A.ncb;
+    const int rb = bid % (C::H / C::RB);
+    bid /= (C::H / C::RB);
+    const int cob = bid % (C::COUT / C::COB);
+    const int n = bid / (C::COUT / C::COB);
+    const int br = C::DILMAX ? n / (A.B * A.F) : n / A.B;
+    const int widx = C::DILMAX ? br * A.F + n % A.F : br;
+    const int dil = C::DILMAX ? A.dil : 1;
+    const int pw = C::DILMAX ? (C::KW / 2) * dil : C::PW;
+    const int h0 = rb * C::RB, w0 = cb * C::WB;
+    const int T = A.T;
+
+    const float* xn = A.x + (size_t)n * C::CIN * C::H * T;
+    const float* wbase = A.wpk + (size_t)widx * C::COUT * C::CIN * C::KH * C::KW + (size_t)cob * C::NST * C::SLAB;
+
+    f32x16 acc[C::MT][C::RT][C::CT];
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+        for (int rt = 0; rt < C::RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < C::CT; ++ct)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[m][rt][ct][k] = 0.f;
+
+    const int abase = wm * (64 * C::MT) + lane * C::MT;
+    const int bbase = lane_h * C::PS + (wr * C::RT) * C::PCW + wc * C::CT * 32 + lane_j;
+
+    load_patch<C>(xn, 0, h0, w0, T, patch(0), wid, lane, pw);
+    load_slab<C>(wbase, slab(0), wid, lane);
+
+    int st = 0;
+    for (int cc = 0; cc < C::NCC; ++cc) {
+        for (int r = 0; r < C::KH; ++r, ++st) {
+            wait_vm0();
+            __syncthreads();
+            if (st + 1 < C::NST) {
+                load_slab<C>(wbase + (size_t)(st + 1) * C::SLAB, slab(st + 1), wid, lane);
+                if (r == C::KH - 1) load_patch<C>(xn, cc + 1, h0, w0, T, patch(cc + 1), wid, lane, pw);
+            }
+            compute_stage<C>(slab(st) + abase, patch(cc) + bbase + r * C::PCW, acc, dil);
+        }
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    if constexpr (C::EPI == 0) {
+        const uint32_t lseed = layer_seed(A.seed, A.layer, br);
+        const int b_in_br = n - br * A.B;
+        const float* bias = A.bias.p[br];
+#pragma unroll
+        for (int m = 0; m < C::MT; ++m) {
+            const int co0 = cob * C::COB + (wm * C::MT + m) * 32;
+#pragma unroll
+            for (int ct = 0; ct < C::CT; ++ct) {
+                const int col = w0 + (wc * C::CT + ct) * 32 + lane_j;
+                if (col >= T) continue;
+#pragma unroll
+                for (int g = 0; g < C::RT / C::POOL; ++g) {
+                    const int hp = (h0 + wr * C::RT) / C::POOL + g;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int co = co0 + acc_row(k, lane_h);
+                        float best = acc[m][g * C::POOL][ct][k];
+                        int am = 0;
+#pragma unroll
+                        for (int a = 1; a < C::POOL; ++a) {
+                            const float v = acc[m][g * C::POOL + a][ct][k];
+                            if (v > best) { best = v; am = a; }
+                        }
+                        float v = best + bias[co];
+                        v = v > 0.f ? v : 0.f;
+                        const size_t o = (((size_t)n * C::COUT + co) * C::HP + hp) * T + col;
+                        if (A.thresh) {
+                            const uint64_t idx = (((uint64_t)b_in_br * C::COUT + co) * C::HP + hp) * T + col;
+                            v = drop_keep(lseed, idx, A.thresh) ? v * A.inv_keep : 0.f;
+                        }
+                        A.y[o] = v;
+                        if (C::POOL > 1 && A.argmax) A.argmax[o] = (uint8_t)am;
+                    }
+                }
+            }
+        }
+    } else {
+        const int pp = A.prev_pool;
+#pragma unroll
+        for (int m = 0; m < C::MT; ++m) {
+            const int co0 = cob * C::COB + (wm * C::MT + m) * 32;
+#pragma unroll
+            for (int ct = 0; ct < C::CT; ++ct) {
+                const int col = w0 + (wc * C::CT + ct) * 32 + lane_j;
+                if (col >= T) continue;
+#pragma unroll
+                for (int rt = 0; rt < C::RT; ++rt) {
+                    const int row = h0 + wr * C::RT + rt;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int co = co0 + acc_row(k, lane_h);
+                        const size_t o = (((size_t)n * C::COUT + co) * C::H + row) * T + col;
+                        float g = acc[m][rt][ct][k];
+                        if (A.xmask) g = (A.xmask[o] != 0.f) ? g * A.inv_keep : 0.f;
+                        if (pp > 1) {
+                            const int am = A.prev_argmax[o];
+                            const size_t base = (((size_t)n * C::COUT + co) * C::H + row) * pp * T + col;
+                            for (int a = 0; a < pp; ++a) A.dx[base + (size_t)a * T] = (a == am) ? g : 0.f;
+                        } else {
+                            A.dx[o] = g;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Pack OIHW weights into the stage-slab order conv_core streams:
+//   [branch][cob][stage = cc*KH + r][cp][s][wm][lane_h][i][m]
+// transposed != 0 packs the backward-data operator: Wc[co_c][ci_c][r][s] = W[ci_c][co_c][KH-1-r][KW-1-s].
+static __global__ void pack_weights_kernel(Ptr2 w, float* __restrict__ dst, int cin_c, int cout_c, int kh, int kw, int cob_sz,
+                                    int ck, int mt, int wm_n, int transposed, long long per_branch, int nbr) {
+    const long long total = per_branch * nbr;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total;
+         o += (long long)gridDim.x * blockDim.x) {
+        const int br = (int)(o / per_branch);
+        long long q = o % per_branch;
+        const int m = (int)(q % mt); q /= mt;
+        const int i = (int)(q % 32); q /= 32;
+        const int h = (int)(q % 2); q /= 2;
+        const int wm = (int)(q % wm_n); q /= wm_n;
+        const int s = (int)(q % kw); q /= kw;
+        const int cp = (int)(q % (ck / 2)); q /= (ck / 2);
+        const int r = (int)(q % kh); q /= kh;
+        const int ncc = cin_c / ck;
+        const int cc = (int)(q % ncc); q /= ncc;
+        const int cob = (int)q;
+        const int co = cob * cob_sz + (wm * mt + m) * 32 + i;
+        const int ci = cc * ck + 2 * cp + h;
+        float v;
+        if (!transposed) {
+            v = w.p[br][(((size_t)co * cin_c + ci) * kh + r) * kw + s];
+        } else {
+            // original tensor is [cout_o = cin_c][cin_o = cout_c][kh][kw]
+            v = w.p[br][(((size_t)ci * cout_c + co) * kh + (kh - 1 - r)) * kw + (kw - 1 - s)];
+        }
+        dst[o] = v;
+    }
+}
+
+// =====================================================================================================
+//                                        backward-weights core
+// =====================================================================================================
+template <int CIN_, int COUT_, int KH_, int KW_, int H_, int MT_, int NS_, int WMW_, int WQ_, int R_, int DILMAX_ = 0>
+struct WgCfg {
+    static constexpr int CIN = CIN_, COUT = COUT_, KH = KH_, KW = KW_, H = H_;
+    static constexpr int DILMAX = DILMAX_;   // > 0: frequency-domain use, taps `dil` apart (see ConvCfg)
+    static constexpr int MT = MT_, NS = NS_, WMW = WMW_, WQ = WQ_, R = R_;
+    static constexpr int NW = WMW * WQ, NT = NW * 64;
+    static constexpr int COB = WMW * MT * 32;
+    static constexpr int G = WQ * NS, Q = KH * KW, NQG = (Q + G - 1) / G;
+    static constexpr int CW = 64;                            // pixels per K-tile: one image row segment
+    static constexpr int PH = KH / 2, PW = KW / 2;
+    static constexpr int RSPAN = KH == 1 ? 1 : (KW - 1 + G - 1) / KW + 1;  // kernel rows a workgroup's shifts touch
+    static constexpr int PRW = RSPAN, PCW = CW + (KW - 1) * (DILMAX ? DILMAX : 1);
+    static constexpr int PS = (PRW * PCW) | 1;               // odd plane stride: lanes (= channels) hit distinct banks
+    static constexpr int ZBUF = COB * CW;                    // dZ tile [COB][64], 16-byte chunks XOR-swizzled by co&15
+    static constexpr int XBUF = ((32 * PS + 63) / 64) * 64;
+    static constexpr int NXI = (XBUF / 64 + NW - 1) / NW;    // X-patch DMA instructions per wave
+    static constexpr int LDS_BYTES = 2 * (ZBUF + XBUF) * 4;
+    static_assert(R == 1, "one image row per K-tile");
+    static_assert(CIN % 32 == 0 && COUT % COB == 0, "tiling");
+    static_assert(COB % 4 == 0 && MT * NS * 16 <= 160, "accumulator budget");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+struct WgArgs {
+    const float* dz;   // [N, COUT, H, T]
+    const float* x;    // [N, CIN, H, T]
+    float* slab;       // [nbr][KS][Q][COUT][CIN]
+    int B, T, ncb;     // column blocks of 64
+    int KS, tiles_per_split, tiles_total;   // per branch
+    int dil, F;        // DILMAX > 0 only: tap spacing; frequency slots (the "branch" grid index is then branch*F + f)
+};
+
+// Stage one K-tile (image row h0, columns w0..w0+63 of sample n):
+//   dZ  [COB][64]            16-byte chunk c of channel co is stored at chunk position c ^ (co & 15)
+//   X   [32][PRW][PCW] (+pad) rows h0+r0-PH .., columns w0-PW .., zero outside the image
+// xrel / xrc: per-lane source offsets of this wave's X-patch DMA instructions, computed once per kernel.
+template <class C>
+__device__ __forceinline__ void wg_load_tile(const WgArgs& A, int br, int cob, int cit, int r0, int tile, float* zb,
+                                             float* xb, int wid, int lane, const int (&xrel)[C::NXI],
+                                             const int (&xrc)[C::NXI]) {
+    const int T = A.T;
+    const int cbk = tile % A.ncb;
+    const int h0 = (tile / A.ncb) % C::H;
+    const int b = tile / (A.ncb * C::H);
+    const int n = C::DILMAX ? ((br / A.F) * A.B + b) * A.F + br % A.F : br * A.B + b;
+    const int w0 = cbk * C::CW;
+    const float* zrow = A.dz + (((size_t)n * C::COUT + (size_t)cob * C::COB) * C::H + h0) * T + w0;
+    const size_t zplane = (size_t)C::H * T;
+    const bool fastz = ((T & 3) == 0) && (w0 + C::CW <= T) && ((reinterpret_cast<uintptr_t>(A.dz) & 15) == 0);
+    if (fastz) {
+        // 16 lanes x 16 B = one row segment; one DMA instruction stages 4 channels (1 KiB, LDS-linear)
+        for (int q = wid; q < C::COB / 4; q += C::NW) {
+            const int co = 4 * q + (lane >> 4);
+            const int c = (lane & 15) ^ (co & 15);
+            glds16(zrow + (size_t)co * zplane + c * 4, zb + q * 256);
+        }
+    } else {
+        for (int q = wid; q < C::COB; q += C::NW) {
+            const int col = (((lane >> 2) ^ (q & 15)) << 2) + (lane & 3);
+            const float* src = (w0 + col < T) ? zrow + (size_t)q * zplane + col : g_zero_page;
+            glds4(src, zb + q * C::CW);
+        }
+    }
+    const int hbase = h0 + r0 - C::PH, wbase = w0 - (C::DILMAX ? (C::KW / 2) * A.dil : C::PW);
+    const bool interior = hbase >= 0 && hbase + C::PRW <= C::H && wbase >= 0 && wbase + C::PCW <= T;
+    const float* xbase = A.x + ((size_t)n * C::CIN + (size_t)cit * 32) * C::H * T + (ptrdiff_t)hbase * T + wbase;
+#pragma unroll
+    for (int i = 0; i < C::NXI; ++i) {
+        const int q = wid + i * C::NW;
+        if (q < C::XBUF / 64) {
+            bool ok = xrel[i] >= 0;
+            if (!interior) {
+                const int hh = hbase + (xrc[i] >> 16), ww = wbase + (xrc[i] & 0xffff);
+                ok = ok && (unsigned)hh < (unsigned)C::H && (unsigned)ww < (unsigned)T;
+            }
+            const float* src = ok ? xbase + xrel[i] : g_zero_page;
+            glds4(src, xb + q * 64);
+        }
+    }
+}
+
+template <class C>
+__global__ void __launch_bounds__(C::NT) wgrad_core(WgArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    auto zbuf = [&](int i) -> float* { return smem + (i & 1) * C::ZBUF; };
+    auto xbuf = [&](int i) -> float* { return smem + 2 * C::ZBUF + (i & 1) * C::XBUF; };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane_j = lane & 31, lane_h = lane >> 5;
+    const int wq = wid % C::WQ, wmw = wid / C::WQ;
+
+    int bid = blockIdx.x;
+    const int qg = bid % C::NQG; bid /= C::NQG;
+    const int cit = bid % (C::CIN / 32); bid /= (C::CIN / 32);
+    const int cob = bid % (C::COUT / C::COB); bid /= (C::COUT / C::COB);
+    const int ks = bid % A.KS;
+    const int br = bid / A.KS;
+
+    const int q0 = qg * C::G;
+    const int r0 = q0 / C::KW;
+    const int t_begin = ks * A.tiles_per_split;
+    int t_end = t_begin + A.tiles_per_split;
+    if (t_end > A.tiles_total) t_end = A.tiles_total;
+
+    f32x16 acc[C::MT][C::NS];
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[m][s][k] = 0.f;
+
+    // X-patch DMA source offsets of this wave (tile independent)
+    int xrel[C::NXI], xrc[C::NXI];
+#pragma unroll
+    for (int i = 0; i < C::NXI; ++i) {
+        const int L = (wid + i * C::NW) * 64 + lane;
+        const int ci = L / C::PS;
+        const int rem = L - ci * C::PS;
+        const int row = rem / C::PCW;
+        const int col = rem - row * C::PCW;
+        const bool ok = ci < 32 && row < C::PRW;
+        xrel[i] = ok ? (ci * C::H + row) * A.T + col : -1;
+        xrc[i] = (row << 16) | col;
+    }
+
+    // per-lane LDS read bases.  A (dZ): channel = lane_j, 4 consecutive pixels per ds_read_b128; the k index of MFMA s
+    // in pixel group g is pixel 8g + 4*lane_h + s for BOTH operands.
+    const int zrowbase = ((wmw * C::MT) * 32 + lane_j) * C::CW;
+    const int zswz = lane_h ^ (lane_j & 15);
+    int xoff[C::NS];
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s) {
+        int q = q0 + wq * C::NS + s;
+        if (q >= C::Q) q = C::Q - 1;   // padded shift: computed, never stored
+        const int rr = q / C::KW, ss = q - rr * C::KW;
+        xoff[s] = lane_j * C::PS + (rr - r0) * C::PCW + (C::DILMAX ? ss * A.dil : ss) + 4 * lane_h;
+    }
+
+    if (t_begin < t_end) wg_load_tile<C>(A, br, cob, cit, r0, t_begin, zbuf(0), xbuf(0), wid, lane, xrel, xrc);
+    int cur = 0;
+    for (int tile = t_begin; tile < t_end; ++tile, cur ^= 1) {
+        wait_vm0();
+        __syncthreads();
+        if (tile + 1 < t_end)
+            wg_load_tile<C>(A, br, cob, cit, r0, tile + 1, zbuf(cur ^ 1), xbuf(cur ^ 1), wid, lane, xrel, xrc);
+        const float* __restrict__ zp = zbuf(cur) + zrowbase;
+        const float* __restrict__ xp = xbuf(cur);
+#pragma unroll
+        for (int g = 0; g < C::CW / 8; ++g) {
+            f32x4 a4[C::MT];
+            const int chunk = (2 * g) ^ zswz;
+#pragma unroll
+            for (int m = 0; m < C::MT; ++m) a4[m] = *reinterpret_cast<const f32x4*>(zp + m * 32 * C::CW + chunk * 4);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                float b[C::NS];
+#pragma unroll
+                for (int s = 0; s < C::NS; ++s) b[s] = xp[xoff[s] + 8 * g + s4];
+#pragma unroll
+                for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+                    for (int s = 0; s < C::NS; ++s)
+                        acc[m][s] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[m][s4], b[s], acc[m][s], 0, 0, 0);
+            }
+        }
+    }
+
+    // partial slab: [br][ks][q][co][ci]
+    float* sl = A.slab + ((size_t)br * A.KS + ks) * C::Q * C::COUT * C::CIN;
+#pragma unroll
+    for (int s = 0; s < C::NS; ++s) {
+        const int q = q0 + wq * C::NS + s;
+        if (q >= C::Q) continue;
+#pragma unroll
+        for (int m = 0; m < C::MT; ++m) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int co = cob * C::COB + (wmw * C::MT + m) * 32 + acc_row(k, lane_h);
+                const int ci = cit * 32 + lane_j;
+                sl[((size_t)q * C::COUT + co) * C::CIN + ci] = acc[m][s][k];
+            }
+        }
+    }
+}
+
+// dw[br][co][ci][r][s] (+)= sum_ks slab[br][ks][q=r*KW+s][co][ci], fixed summation order
+static __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, MPtr2 dw, int KS, int Q, int cout, int cin,
+                                    int accumulate, int nbr) {
+    const long long per = (long long)Q * cout * cin;
+    const long long total = per * nbr;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total;
+         o += (long long)gridDim.x * blockDim.x) {
+        const int br = (int)(o / per);
+        const long long e = o % per;
+        const int ci = (int)(e % cin);
+        const int co = (int)((e / cin) % cout);
+        const int q = (int)(e / ((long long)cin * cout));
+        const float* sp = slab + (size_t)br * KS * per + e;
+        float s = 0.f;
+        for (int k = 0; k < KS; ++k) s += sp[(size_t)k * per];
+        float* d = dw.p[br] + ((size_t)co * cin + ci) * Q + q;
+        *d = accumulate ? *d + s : s;
+    }
+}
+
+
+static int device_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+            cus = n;
+        else
+            cus = 256;   // MI355X; also the answer when no device is visible (workspace queries on a CPU box)
+    }
+    return cus;
+}
+
+// Split-K factor for backward-weights.  One workgroup per CU is resident (LDS), every workgroup does the same
+// work, so the launch runs in ceil(WGs / CUs) rounds: pick KS that wastes the least of the last round and of the
+// last (ragged) split, among launches of >= 2 rounds' worth of workgroups, preferring the smaller slab on ties.
+template <class C>
+static int wg_pick_ks(const ConvArgs& a, int* tiles_total, int* tps) {
+    const int ncb = ceil_div(a.T, C::CW);
+    const int total = a.B * C::H * ncb;
+    const int base = C::NQG * (C::CIN / 32) * (C::COUT / C::COB) * a.nbr;
+    const int cus = device_cus();
+    int best_ks = 1;
+    double best_eff = -1.0;
+    const int ks_max = total < 256 ? total : 256;
+    for (int ks = 1; ks <= ks_max; ++ks) {
+        const int per = ceil_div(total, ks);
+        if (ceil_div(total, per) != ks) continue;              // not a distinct split
+        const long long wgs = (long long)base * ks;
+        const long long rounds = (wgs + cus - 1) / cus;
+        double eff = (double)wgs / (double)(rounds * cus) * ((double)total / ((double)ks * per));
+        if (wgs < cus) eff *= 0.5;                               // do not leave CUs without a workgroup
+        if (eff > best_eff + 0.02 || (eff > best_eff - 1e-9 && wgs >= 2LL * cus && (long long)base * best_ks < 2LL * cus)) {
+            best_eff = eff;
+            best_ks = ks;
+        }
+        if (best_eff > 0.985 && (long long)base * best_ks >= 2LL * cus) break;
+    }
+    const int per = ceil_div(total, best_ks);
+    *tiles_total = total;
+    *tps = per;
+    return ceil_div(total, per);
+}
+
+
+}  // namespace zns

@@ -1,0 +1,571 @@
+// Frequency-domain (overlap-save) form of the cv2..cv6 convolutions: same fp32 results, ~6x fewer MFMA FLOPs.
+//
+// The kernels are wide along time (kw = 13..21 taps) and time is long (T = 313..626), so the time axis is cut
+// into 64-sample windows that overlap by kw-1 (V = 65-kw valid outputs per window).  A 64-point real DFT of each
+// window turns the kw-tap correlation along time into ONE complex multiply per frequency; the correlation over
+// input channels and kernel ROWS stays a dense contraction, done on the fp32 matrix cores by the SAME conv_core /
+// wgrad_core templates as the direct path, instantiated as a 1-D correlation with kh taps spaced NB positions
+// apart along the flattened (row, window) axis, with 2x real-embedded channels (re, im) and one weight set per
+// frequency.  Per output window the direct form costs V*kw MACs per (ci, co, r), this form 4*32 (32 complex
+// bins, 4 real MACs each): 5.1x (cv2) .. 7.0x (cv6) fewer.  Everything stays fp32 (no reduced-precision
+// shortcut): error vs the direct kernels ~1e-6 of the tensor max.
+//
+//   forward        y  = IDFT( G  . DFT(x windows) ),   G [f] = sum_s W[s]        e^{+i th f s}
+//   backward-data  dx = IDFT( G' . DFT(dz windows) ),  G'[f] = sum_s W[kw-1-s]   e^{+i th f s}, roles of ci/co swapped
+//   backward-wts   dW[s] = IDFT_s( sum_windows conj(DFT(dz V-block, zero padded)) . DFT(x window) )
+//
+// Spectra live in the workspace as S[sample][f = 0..31][2C][P], P = H*NB; slot f = 0 packs the two real bins
+// (DC in "re", Nyquist in "im").  The DFT/IDFT passes are direct 64-point sums on the vector ALU (HBM-bound,
+// <5 % of the step); fusing them into the GEMM epilogues is the next step.
+#include "zns_conv_core.h"
+
+namespace zns {
+
+constexpr int FN = 64, FF = 32, FDIL = 16;
+
+__device__ __forceinline__ void twiddle_init(float2* tw) {
+    // tw[k] = (cos, sin)(2 pi k / 64), filled by the first 64 threads
+    if (threadIdx.x < FN) {
+        float s, c;
+        sincospif((float)threadIdx.x / 32.0f, &s, &c);
+        tw[threadIdx.x] = make_float2(c, s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// x [nb, C, H, T] -> S [nb][FF][2C][P].  Window of block b starts at column b*V - off and has `valid` live
+// samples (64 for the overlapped correlation windows, V for the zero-padded blocks of backward-weights' dZ).
+__global__ void __launch_bounds__(256) spec_fwd_kernel(const float* __restrict__ x, float* __restrict__ S, int C,
+                                                       int H, int T, int V, int NB, int off, int valid, int chunks) {
+    __shared__ float2 tw[FN];
+    twiddle_init(tw);
+    __syncthreads();
+    const int P = H * NB;
+    const int chunk = blockIdx.x % chunks;
+    const int plane = blockIdx.x / chunks;          // n * C + c
+    const int c = plane % C, n = plane / C;
+    const int p = chunk * 256 + threadIdx.x;
+    if (p >= P) return;
+    const int h = p / NB, b = p - h * NB;
+    const float* row = x + ((size_t)plane * H + h) * T;
+    const int c0 = b * V - off;
+    float xw[FN];
+#pragma unroll
+    for (int m = 0; m < FN; ++m) {
+        const int col = c0 + m;
+        xw[m] = (m < valid && col >= 0 && col < T) ? row[col] : 0.f;
+    }
+    float* out = S + (((size_t)n * FF) * 2 * C + 2 * c) * P + p;
+    const size_t fstride = (size_t)2 * C * P;
+    {
+        float dc = 0.f, ny = 0.f;
+#pragma unroll
+        for (int m = 0; m < FN; m += 2) {
+            dc += xw[m] + xw[m + 1];
+            ny += xw[m] - xw[m + 1];
+        }
+        out[0] = dc;
+        out[P] = ny;
+    }
+    for (int f = 1; f < FF; ++f) {
+        float re = 0.f, im = 0.f;
+#pragma unroll
+        for (int m = 0; m < FN; ++m) {
+            const float2 t = tw[(f * m) & (FN - 1)];
+            re = fmaf(xw[m], t.x, re);
+            im = fmaf(-xw[m], t.y, im);
+        }
+        out[f * fstride] = re;
+        out[f * fstride + P] = im;
+    }
+}
+
+// S [nb][FF][2C][P] -> z [nb, C, H, T]: 64-point inverse real DFT of each window, first V samples kept.
+__global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__ S, float* __restrict__ z, int C, int H,
+                                                       int T, int V, int NB, int chunks) {
+    __shared__ float2 tw[FN];
+    twiddle_init(tw);
+    __syncthreads();
+    const int P = H * NB;
+    const int chunk = blockIdx.x % chunks;
+    const int plane = blockIdx.x / chunks;
+    const int c = plane % C, n = plane / C;
+    const int p = chunk * 256 + threadIdx.x;
+    if (p >= P) return;
+    const int h = p / NB, b = p - h * NB;
+    const float* in = S + (((size_t)n * FF) * 2 * C + 2 * c) * P + p;
+    const size_t fstride = (size_t)2 * C * P;
+    float yr[FF], yi[FF];
+#pragma unroll
+    for (int f = 0; f < FF; ++f) {
+        yr[f] = in[f * fstride];
+        yi[f] = in[f * fstride + P];
+    }
+    float* row = z + ((size_t)plane * H + h) * T + b * V;
+    const int nv = min(V, T - b * V);
+    for (int v = 0; v < nv; ++v) {
+        float acc = 0.f;
+#pragma unroll
+        for (int f = 1; f < FF; ++f) {
+            const float2 t = tw[(f * v) & (FN - 1)];
+            acc = fmaf(yr[f], t.x, acc);
+            acc = fmaf(-yi[f], t.y, acc);
+        }
+        const float r = yr[0] + ((v & 1) ? -yi[0] : yi[0]) + 2.0f * acc;
+        row[v] = r * (1.0f / FN);
+    }
+}
+
+// z [nb, C, H, T] (raw conv output, no bias) -> y = dropout(relu(maxpool(z) + bias)), arg-max rows
+__global__ void pool_relu_drop_kernel(const float* __restrict__ z, Ptr2 bias, float* __restrict__ y,
+                                      uint8_t* __restrict__ argmax, int B, int C, int H, int T, int pool,
+                                      uint32_t thresh, float inv_keep, uint32_t seed, int layer, long long total) {
+    const int Hp = H / pool;
+    const long long per_branch = (long long)B * C * Hp * T;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total;
+         o += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(o % T);
+        long long q = o / T;
+        const int hp = (int)(q % Hp);
+        q /= Hp;
+        const int co = (int)(q % C);
+        const int n = (int)(q / C);
+        const int br = n / B;
+        const float* zp = z + (((size_t)n * C + co) * H + (size_t)hp * pool) * T + t;
+        float best = zp[0];
+        int am = 0;
+        for (int a = 1; a < pool; ++a) {
+            const float v = zp[(size_t)a * T];
+            if (v > best) { best = v; am = a; }
+        }
+        float v = best + bias.p[br][co];
+        v = v > 0.f ? v : 0.f;
+        if (thresh) v = drop_keep(layer_seed(seed, layer, br), (uint64_t)(o - (long long)br * per_branch), thresh) ? v * inv_keep : 0.f;
+        y[o] = v;
+        if (argmax && pool > 1) argmax[o] = (uint8_t)am;
+    }
+}
+
+// dxraw [nb, C, H, T] -> dx: ReLU/dropout mask of the previous layer's output x, then max-unpool through its arg-max
+__global__ void mask_unpool_kernel(const float* __restrict__ dxraw, const float* __restrict__ x, float inv_keep,
+                                   const uint8_t* __restrict__ prev_argmax, int pp, float* __restrict__ dx, int T,
+                                   long long total) {
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total;
+         o += (long long)gridDim.x * blockDim.x) {
+        float g = dxraw[o];
+        if (x) g = (x[o] != 0.f) ? g * inv_keep : 0.f;
+        if (pp > 1) {
+            const int am = prev_argmax[o];
+            const long long rowi = o / T;
+            const int t = (int)(o - rowi * T);
+            float* d = dx + (size_t)rowi * pp * T + t;
+            for (int a = 0; a < pp; ++a) d[(size_t)a * T] = (a == am) ? g : 0.f;
+        } else {
+            dx[o] = g;
+        }
+    }
+}
+
+// Frequency weights in conv_core's slab order for the real-embedded operator (CIN_c = 2*cin_c, COUT_c = 2*cout_c,
+// 1 x kh taps):  [branch*FF + f][cob][cc][cp][tap][wm][lane_h][i][m].
+__global__ void pack_freq_weights_kernel(Ptr2 w, float* __restrict__ dst, int cin_c, int cout_c, int kh, int kw,
+                                         int cob_sz, int ck, int mt, int wm_n, int transposed, long long per_wf,
+                                         int nbr) {
+    const long long total = per_wf * FF * nbr;
+    const int CI2 = 2 * cin_c;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total;
+         o += (long long)gridDim.x * blockDim.x) {
+        const int widx = (int)(o / per_wf);
+        const int br = widx / FF, f = widx % FF;
+        long long q = o % per_wf;
+        const int m = (int)(q % mt); q /= mt;
+        const int i = (int)(q % 32); q /= 32;
+        const int h = (int)(q % 2); q /= 2;
+        const int wm = (int)(q % wm_n); q /= wm_n;
+        const int tap = (int)(q % kh); q /= kh;
+        const int cp = (int)(q % (ck / 2)); q /= (ck / 2);
+        const int ncc = CI2 / ck;
+        const int cc = (int)(q % ncc); q /= ncc;
+        const int cob = (int)q;
+        const int cop = cob * cob_sz + (wm * mt + m) * 32 + i;   // real-embedded output channel
+        const int cip = cc * ck + 2 * cp + h;                     // real-embedded input channel
+        const int co = cop >> 1, a = cop & 1, ci = cip >> 1, c = cip & 1;
+        // taps along time of the (co, ci, tap) kernel row, as the core sees them
+        const float* wr;
+        int sstep;
+        if (!transposed) {
+            wr = w.p[br] + (((size_t)co * cin_c + ci) * kh + tap) * kw;                     // W[co][ci][tap][s]
+            sstep = 1;
+        } else {
+            // original tensor [cout_o = cin_c][cin_o = cout_c][kh][kw]; flipped in both kernel axes
+            wr = w.p[br] + (((size_t)ci * cout_c + co) * kh + (kh - 1 - tap)) * kw + (kw - 1);
+            sstep = -1;
+        }
+        float v;
+        if (f == 0) {
+            float g0 = 0.f, g32 = 0.f;
+            for (int s = 0; s < kw; ++s) {
+                const float ws = wr[s * sstep];
+                g0 += ws;
+                g32 += (s & 1) ? -ws : ws;
+            }
+            v = (a == 0 && c == 0) ? g0 : ((a == 1 && c == 1) ? g32 : 0.f);
+        } else {
+            float gr = 0.f, gi = 0.f;
+            for (int s = 0; s < kw; ++s) {
+                float sn, cs;
+                sincospif((float)((f * s) & (FN - 1)) / 32.0f, &sn, &cs);
+                const float ws = wr[s * sstep];
+                gr = fmaf(ws, cs, gr);
+                gi = fmaf(ws, sn, gi);
+            }
+            v = (a == c) ? gr : (a == 1 ? gi : -gi);
+        }
+        dst[o] = v;
+    }
+}
+
+// slab [br*FF + f][ks][tap][2*cout][2*cin] (the four real products of conj(dZ).X) -> dW[co][ci][tap][s]
+__global__ void wgrad_spec_reduce_kernel(const float* __restrict__ slab, MPtr2 dw, int KS, int cout, int cin, int kh,
+                                         int kw, int accumulate, int nbr) {
+    __shared__ float2 tw[FN];
+    twiddle_init(tw);
+    __syncthreads();
+    const long long per = (long long)cout * cin * kh;
+    const long long total = per * nbr;
+    const int CO2 = 2 * cout, CI2 = 2 * cin;
+    const size_t per_ks = (size_t)kh * CO2 * CI2;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total;
+         o += (long long)gridDim.x * blockDim.x) {
+        const int br = (int)(o / per);
+        long long e = o % per;
+        const int ci = (int)(e % cin); e /= cin;
+        const int co = (int)(e % cout);
+        const int tap = (int)(e / cout);
+        float cr[FF], cim[FF];
+        for (int f = 0; f < FF; ++f) {
+            float g00 = 0.f, g01 = 0.f, g10 = 0.f, g11 = 0.f;
+            const float* sp = slab + ((size_t)(br * FF + f) * KS) * per_ks + ((size_t)tap * CO2 + 2 * co) * CI2 + 2 * ci;
+            for (int k = 0; k < KS; ++k) {
+                const float* q = sp + (size_t)k * per_ks;
+                g00 += q[0]; g01 += q[1]; g10 += q[CI2]; g11 += q[CI2 + 1];
+            }
+            if (f == 0) { cr[0] = g00; cim[0] = g11; }           // DC and Nyquist, both real
+            else { cr[f] = g00 + g11; cim[f] = g01 - g10; }       // conj(dz) * x
+        }
+        float* d = dw.p[br] + (((size_t)co * cin + ci) * kh + tap) * kw;
+        for (int s = 0; s < kw; ++s) {
+            float acc = 0.f;
+#pragma unroll
+            for (int f = 1; f < FF; ++f) {
+                const float2 t = tw[(f * s) & (FN - 1)];
+                acc = fmaf(cr[f], t.x, acc);
+                acc = fmaf(-cim[f], t.y, acc);
+            }
+            const float r = (cr[0] + ((s & 1) ? -cim[0] : cim[0]) + 2.0f * acc) * (1.0f / FN);
+            d[s] = accumulate ? d[s] + r : r;
+        }
+    }
+}
+
+// =====================================================================================================
+//                                          instances + dispatch
+// =====================================================================================================
+//                  CIN' COUT' KH KW(taps) H  MT RT CT WM WR WC CK POOL EPI DILMAX
+using FF2 = ConvCfg<128, 128, 1, 7, 1, 4, 1, 2, 1, 1, 4, 8, 1, 1, FDIL>;
+using FF3 = ConvCfg<128, 256, 1, 5, 1, 4, 1, 2, 2, 1, 2, 8, 1, 1, FDIL>;
+using FF4 = ConvCfg<256, 256, 1, 9, 1, 4, 1, 2, 2, 1, 2, 4, 1, 1, FDIL>;
+using FF5 = ConvCfg<256, 512, 1, 3, 1, 4, 1, 1, 2, 1, 3, 16, 1, 1, FDIL>;
+using FF6 = ConvCfg<512, 512, 1, 5, 1, 4, 1, 1, 2, 1, 3, 8, 1, 1, FDIL>;
+using FD2 = FF2;
+using FD3 = ConvCfg<256, 128, 1, 5, 1, 4, 1, 2, 1, 1, 3, 8, 1, 1, FDIL>;
+using FD4 = FF4;
+using FD5 = ConvCfg<512, 256, 1, 3, 1, 4, 1, 1, 2, 1, 3, 16, 1, 1, FDIL>;
+using FD6 = FF6;
+//                 CIN' COUT' KH KW(taps) H  MT NS WMW WQ R DILMAX
+using FW2 = WgCfg<128, 128, 1, 7, 1, 2, 4, 2, 2, 1, FDIL>;
+using FW3 = WgCfg<128, 256, 1, 5, 1, 2, 3, 2, 2, 1, FDIL>;
+using FW4 = WgCfg<256, 256, 1, 9, 1, 2, 3, 2, 3, 1, FDIL>;
+using FW5 = WgCfg<256, 512, 1, 3, 1, 2, 3, 4, 1, 1, FDIL>;
+using FW6 = WgCfg<512, 512, 1, 5, 1, 2, 3, 2, 2, 1, FDIL>;
+
+struct FftGeom {
+    int V, NB, P, nb;
+};
+
+static int fft_layer_of(const ConvArgs& a) {
+    struct L { int cin, cout, kh, kw, H; };
+    static const L tab[] = {{64, 64, 7, 13, 96}, {64, 128, 5, 15, 32}, {128, 128, 9, 17, 32}, {128, 256, 3, 19, 8},
+                            {256, 256, 5, 21, 8}};
+    for (int i = 0; i < 5; ++i)
+        if (tab[i].cin == a.cin && tab[i].cout == a.cout && tab[i].kh == a.kh && tab[i].kw == a.kw && tab[i].H == a.H)
+            return i + 2;
+    return -1;
+}
+
+static FftGeom geom(const ConvArgs& a) {
+    FftGeom g;
+    g.V = FN - a.kw + 1;
+    g.NB = ceil_div(a.T, g.V);
+    g.P = a.H * g.NB;
+    g.nb = a.nbr * a.B;
+    return g;
+}
+
+bool fft_supported(const ConvArgs& a) {
+    if (fft_layer_of(a) < 0 || a.nbr < 1 || a.nbr > 2) return false;
+    const FftGeom g = geom(a);
+    return g.NB <= FDIL && a.T >= 32;
+}
+
+static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct FftWs {
+    size_t s_in, s_out, z, wf, slab, total;
+};
+
+template <class W>
+static int fwg_pick_ks(const ConvArgs& a, const FftGeom& g, int* tiles_total, int* tps) {
+    ConvArgs t = a;
+    t.T = g.P;           // K tiles run over the flattened axis
+    t.nbr = a.nbr * FF;  // one accumulation per (branch, frequency)
+    return wg_pick_ks<W>(t, tiles_total, tps);
+}
+
+template <class W>
+static size_t fwg_slab_floats(const ConvArgs& a, const FftGeom& g) {
+    int tt, tps;
+    const int ks = fwg_pick_ks<W>(a, g, &tt, &tps);
+    return (size_t)a.nbr * FF * ks * W::Q * W::COUT * W::CIN;
+}
+
+static FftWs fft_ws(const ConvArgs& a) {
+    const FftGeom g = geom(a);
+    FftWs w{};
+    const size_t cmax = (size_t)(a.cin > a.cout ? a.cin : a.cout);
+    const size_t spec = (size_t)g.nb * FF * 2 * cmax * g.P * sizeof(float);
+    w.s_in = 0;
+    w.s_out = align_up(spec);
+    w.z = w.s_out + align_up(spec);
+    w.wf = w.z + align_up((size_t)g.nb * cmax * a.H * a.T * sizeof(float));
+    const size_t wfb = (size_t)a.nbr * FF * 4 * a.cout * a.cin * a.kh * sizeof(float);
+    size_t slab = 0;
+    switch (fft_layer_of(a)) {
+        case 2: slab = fwg_slab_floats<FW2>(a, g); break;
+        case 3: slab = fwg_slab_floats<FW3>(a, g); break;
+        case 4: slab = fwg_slab_floats<FW4>(a, g); break;
+        case 5: slab = fwg_slab_floats<FW5>(a, g); break;
+        case 6: slab = fwg_slab_floats<FW6>(a, g); break;
+    }
+    slab *= sizeof(float);
+    w.slab = w.wf;   // backward-weights does not need the packed frequency weights: same region
+    w.total = w.wf + align_up(wfb > slab ? wfb : slab);
+    return w;
+}
+
+size_t fft_workspace_bytes(const ConvArgs& a) { return fft_supported(a) ? fft_ws(a).total : 0; }
+
+static int run_spec_fwd(const float* x, float* S, int nb, int C, int H, int T, const FftGeom& g, int off, int valid,
+                        hipStream_t st) {
+    const int chunks = ceil_div(g.P, 256);
+    hipLaunchKernelGGL(spec_fwd_kernel, dim3((unsigned)((size_t)nb * C * chunks)), dim3(256), 0, st, x, S, C, H, T, g.V,
+                       g.NB, off, valid, chunks);
+    ZNS_LAUNCH_CHECK();
+    return ZNS_OK;
+}
+
+static int run_spec_inv(const float* S, float* z, int nb, int C, int H, int T, const FftGeom& g, hipStream_t st) {
+    const int chunks = ceil_div(g.P, 256);
+    hipLaunchKernelGGL(spec_inv_kernel, dim3((unsigned)((size_t)nb * C * chunks)), dim3(256), 0, st, S, z, C, H, T, g.V,
+                       g.NB, chunks);
+    ZNS_LAUNCH_CHECK();
+    return ZNS_OK;
+}
+
+template <class C>
+static int set_lds_f(void (*kern)(CoreArgs)) {
+    static bool done = false;
+    if (!done) {
+        ZNS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        done = true;
+    }
+    return ZNS_OK;
+}
+template <class C>
+static int set_lds_fw(void (*kern)(WgArgs)) {
+    static bool done = false;
+    if (!done) {
+        ZNS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
+        done = true;
+    }
+    return ZNS_OK;
+}
+
+// S_in [nb*FF][CIN'][P] -> S_out [nb*FF][COUT'][P] with the frequency weights of `w`
+template <class C>
+static int run_fconv(const ConvArgs& a, const FftGeom& g, Ptr2 w, int transposed, const float* s_in, float* s_out,
+                     float* wf, int probe_kind, hipStream_t st) {
+    // pack: the core's CIN/COUT are the real-embedded channel counts
+    const int cin_c = C::CIN / 2, cout_c = C::COUT / 2;
+    const long long per_wf = (long long)C::COUT * C::CIN * C::KW;
+    const long long total = per_wf * FF * a.nbr;
+    const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    hipLaunchKernelGGL(pack_freq_weights_kernel, dim3(blocks), dim3(256), 0, st, w, wf, cin_c, cout_c, C::KW, a.kw,
+                       C::COB, C::CK, C::MT, C::WM, transposed, per_wf, a.nbr);
+    ZNS_LAUNCH_CHECK();
+    int rc = set_lds_f<C>(conv_core<C>);
+    if (rc) return rc;
+    CoreArgs A{};
+    A.x = s_in;
+    A.wpk = wf;
+    A.dx = s_out;
+    A.xmask = nullptr;
+    A.inv_keep = 1.f;
+    A.prev_pool = 1;
+    A.B = a.B;
+    A.T = g.P;
+    A.N = g.nb * FF;
+    A.F = FF;
+    A.dil = g.NB;
+    A.ncb = ceil_div(g.P, C::WB);
+    const long long blocks2 = (long long)A.N * A.ncb * (C::COUT / C::COB);
+    const bool probe = probe_match(probe_kind, a.cin, a.cout, a.kh);
+    const int slot = probe ? g_probe.count % g_probe.n : 0;
+    if (probe) ZNS_HIP(hipEventRecord(g_probe.start[slot], st));
+    hipLaunchKernelGGL(conv_core<C>, dim3((unsigned)blocks2), dim3(C::NT), C::LDS_BYTES, st, A);
+    ZNS_LAUNCH_CHECK();
+    if (probe) { ZNS_HIP(hipEventRecord(g_probe.stop[slot], st)); ++g_probe.count; }
+    return ZNS_OK;
+}
+
+template <class C>
+static int fft_fwd_t(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, uint8_t* argmax, float drop_p,
+                     uint32_t seed, int layer, void* ws, size_t ws_bytes, hipStream_t st) {
+    const FftGeom g = geom(a);
+    const FftWs L = fft_ws(a);
+    if (ws_bytes < L.total) { set_error("conv fwd (fft): workspace %zu < %zu", ws_bytes, L.total); return ZNS_ERR_WORKSPACE; }
+    char* base = (char*)ws;
+    float* s_in = (float*)(base + L.s_in);
+    float* s_out = (float*)(base + L.s_out);
+    float* z = (float*)(base + L.z);
+    float* wf = (float*)(base + L.wf);
+    int rc = run_spec_fwd(x, s_in, g.nb, a.cin, a.H, a.T, g, a.kw / 2, FN, st);
+    if (rc) return rc;
+    rc = run_fconv<C>(a, g, w, 0, s_in, s_out, wf, 0, st);
+    if (rc) return rc;
+    rc = run_spec_inv(s_out, z, g.nb, a.cout, a.H, a.T, g, st);
+    if (rc) return rc;
+    const long long total = (long long)g.nb * a.cout * (a.H / a.pool) * a.T;
+    const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+    const uint32_t thresh = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
+    const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
+    hipLaunchKernelGGL(pool_relu_drop_kernel, dim3(blocks), dim3(256), 0, st, z, bias, y, argmax, a.B, a.cout, a.H, a.T,
+                       a.pool, thresh, inv_keep, seed, layer, total);
+    ZNS_LAUNCH_CHECK();
+    return ZNS_OK;
+}
+
+template <class C>
+static int fft_dgrad_t(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, const float* x, float inv_keep,
+                       const uint8_t* prev_argmax, int prev_pool, void* ws, size_t ws_bytes, hipStream_t st) {
+    const FftGeom g = geom(a);
+    const FftWs L = fft_ws(a);
+    if (ws_bytes < L.total) { set_error("conv dgrad (fft): workspace %zu < %zu", ws_bytes, L.total); return ZNS_ERR_WORKSPACE; }
+    char* base = (char*)ws;
+    float* s_in = (float*)(base + L.s_in);
+    float* s_out = (float*)(base + L.s_out);
+    float* z = (float*)(base + L.z);
+    float* wf = (float*)(base + L.wf);
+    int rc = run_spec_fwd(dz, s_in, g.nb, a.cout, a.H, a.T, g, a.kw / 2, FN, st);
+    if (rc) return rc;
+    rc = run_fconv<C>(a, g, w, 1, s_in, s_out, wf, 1, st);
+    if (rc) return rc;
+    const bool plain = (x == nullptr && prev_pool == 1);
+    rc = run_spec_inv(s_out, plain ? dx : z, g.nb, a.cin, a.H, a.T, g, st);
+    if (rc || plain) return rc;
+    const long long total = (long long)g.nb * a.cin * a.H * a.T;
+    const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+    hipLaunchKernelGGL(mask_unpool_kernel, dim3(blocks), dim3(256), 0, st, z, x, inv_keep, prev_argmax, prev_pool, dx,
+                       a.T, total);
+    ZNS_LAUNCH_CHECK();
+    return ZNS_OK;
+}
+
+template <class W>
+static int fft_wgrad_t(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, int accumulate, void* ws,
+                       size_t ws_bytes, hipStream_t st) {
+    const FftGeom g = geom(a);
+    const FftWs L = fft_ws(a);
+    if (ws_bytes < L.total) { set_error("conv wgrad (fft): workspace %zu < %zu", ws_bytes, L.total); return ZNS_ERR_WORKSPACE; }
+    char* base = (char*)ws;
+    float* sx = (float*)(base + L.s_in);
+    float* sz = (float*)(base + L.s_out);
+    float* slab = (float*)(base + L.slab);
+    int rc = run_spec_fwd(x, sx, g.nb, a.cin, a.H, a.T, g, a.kw / 2, FN, st);   // correlation windows of the input
+    if (rc) return rc;
+    rc = run_spec_fwd(dz, sz, g.nb, a.cout, a.H, a.T, g, 0, g.V, st);           // zero-padded V-blocks of dZ
+    if (rc) return rc;
+    rc = set_lds_fw<W>(wgrad_core<W>);
+    if (rc) return rc;
+    WgArgs A{};
+    A.dz = sz;
+    A.x = sx;
+    A.slab = slab;
+    A.B = a.B;
+    A.T = g.P;
+    A.ncb = ceil_div(g.P, W::CW);
+    A.F = FF;
+    A.dil = g.NB;
+    A.KS = fwg_pick_ks<W>(a, g, &A.tiles_total, &A.tiles_per_split);
+    const long long blocks = (long long)W::NQG * (W::CIN / 32) * (W::COUT / W::COB) * A.KS * a.nbr * FF;
+    const bool probe = probe_match(2, a.cin, a.cout, a.kh);
+    const int slot = probe ? g_probe.count % g_probe.n : 0;
+    if (probe) ZNS_HIP(hipEventRecord(g_probe.start[slot], st));
+    hipLaunchKernelGGL(wgrad_core<W>, dim3((unsigned)blocks), dim3(W::NT), W::LDS_BYTES, st, A);
+    ZNS_LAUNCH_CHECK();
+    if (probe) { ZNS_HIP(hipEventRecord(g_probe.stop[slot], st)); ++g_probe.count; }
+    const long long total = (long long)a.nbr * a.cout * a.cin * a.kh;
+    const int rblocks = (int)((total + 127) / 128 > 16384 ? 16384 : (total + 127) / 128);
+    hipLaunchKernelGGL(wgrad_spec_reduce_kernel, dim3(rblocks), dim3(128), 0, st, (const float*)slab, dw, A.KS, a.cout,
+                       a.cin, a.kh, a.kw, accumulate, a.nbr);
+    ZNS_LAUNCH_CHECK();
+    return ZNS_OK;
+}
+
+int fft_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, uint8_t* argmax, float drop_p,
+            uint32_t seed, int layer, void* ws, size_t ws_bytes, hipStream_t st) {
+    switch (fft_layer_of(a)) {
+        case 2: return fft_fwd_t<FF2>(a, x, w, bias, y, argmax, drop_p, seed, layer, ws, ws_bytes, st);
+        case 3: return fft_fwd_t<FF3>(a, x, w, bias, y, argmax, drop_p, seed, layer, ws, ws_bytes, st);
+        case 4: return fft_fwd_t<FF4>(a, x, w, bias, y, argmax, drop_p, seed, layer, ws, ws_bytes, st);
+        case 5: return fft_fwd_t<FF5>(a, x, w, bias, y, argmax, drop_p, seed, layer, ws, ws_bytes, st);
+        case 6: return fft_fwd_t<FF6>(a, x, w, bias, y, argmax, drop_p, seed, layer, ws, ws_bytes, st);
+    }
+    return ZNS_ERR_ARG;
+}
+
+int fft_dgrad(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, const float* x, float inv_keep,
+              const uint8_t* prev_argmax, int prev_pool, void* ws, size_t ws_bytes, hipStream_t st) {
+    switch (fft_layer_of(a)) {
+        case 2: return fft_dgrad_t<FD2>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
+        case 3: return fft_dgrad_t<FD3>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
+        case 4: return fft_dgrad_t<FD4>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
+        case 5: return fft_dgrad_t<FD5>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
+        case 6: return fft_dgrad_t<FD6>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
+    }
+    return ZNS_ERR_ARG;
+}
+
+int fft_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, int accumulate, void* ws, size_t ws_bytes,
+              hipStream_t st) {
+    switch (fft_layer_of(a)) {
+        case 2: return fft_wgrad_t<FW2>(a, dz, x, dw, accumulate, ws, ws_bytes, st);
+        case 3: return fft_wgrad_t<FW3>(a, dz, x, dw, accumulate, ws, ws_bytes, st);
+        case 4: return fft_wgrad_t<FW4>(a, dz, x, dw, accumulate, ws, ws_bytes, st);
+        case 5: return fft_wgrad_t<FW5>(a, dz, x, dw, accumulate, ws, ws_bytes, st);
+        case 6: return fft_wgrad_t<FW6>(a, dz, x, dw, accumulate, ws, ws_bytes, st);
+    }
+    return ZNS_ERR_ARG;
+}
+
+}  // namespace zns
