@@ -18,6 +18,7 @@
 // (DC in "re", Nyquist in "im").  The DFT/IDFT passes are direct 64-point sums on the vector ALU (HBM-bound,
 // <5 % of the step); fusing them into the GEMM epilogues is the next step.
 #include "zns_conv_core.h"
+#include "zns_fft64.h"
 
 namespace zns {
 
@@ -37,9 +38,6 @@ __device__ __forceinline__ void twiddle_init(float2* tw) {
 // samples (64 for the overlapped correlation windows, V for the zero-padded blocks of backward-weights' dZ).
 __global__ void __launch_bounds__(256) spec_fwd_kernel(const float* __restrict__ x, float* __restrict__ S, int C,
                                                        int H, int T, int V, int NB, int off, int valid, int chunks) {
-    __shared__ float2 tw[FN];
-    twiddle_init(tw);
-    __syncthreads();
     const int P = H * NB;
     const int chunk = blockIdx.x % chunks;
     const int plane = blockIdx.x / chunks;          // n * C + c
@@ -57,35 +55,18 @@ __global__ void __launch_bounds__(256) spec_fwd_kernel(const float* __restrict__
     }
     float* out = S + (((size_t)n * FF) * 2 * C + 2 * c) * P + p;
     const size_t fstride = (size_t)2 * C * P;
-    {
-        float dc = 0.f, ny = 0.f;
+    float sr[FF], si[FF];
+    rfft64(xw, sr, si);
 #pragma unroll
-        for (int m = 0; m < FN; m += 2) {
-            dc += xw[m] + xw[m + 1];
-            ny += xw[m] - xw[m + 1];
-        }
-        out[0] = dc;
-        out[P] = ny;
-    }
-    for (int f = 1; f < FF; ++f) {
-        float re = 0.f, im = 0.f;
-#pragma unroll
-        for (int m = 0; m < FN; ++m) {
-            const float2 t = tw[(f * m) & (FN - 1)];
-            re = fmaf(xw[m], t.x, re);
-            im = fmaf(-xw[m], t.y, im);
-        }
-        out[f * fstride] = re;
-        out[f * fstride + P] = im;
+    for (int f = 0; f < FF; ++f) {
+        out[f * fstride] = sr[f];
+        out[f * fstride + P] = si[f];
     }
 }
 
 // S [nb][FF][2C][P] -> z [nb, C, H, T]: 64-point inverse real DFT of each window, first V samples kept.
 __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__ S, float* __restrict__ z, int C, int H,
                                                        int T, int V, int NB, int chunks) {
-    __shared__ float2 tw[FN];
-    twiddle_init(tw);
-    __syncthreads();
     const int P = H * NB;
     const int chunk = blockIdx.x % chunks;
     const int plane = blockIdx.x / chunks;
@@ -103,17 +84,11 @@ __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__
     }
     float* row = z + ((size_t)plane * H + h) * T + b * V;
     const int nv = min(V, T - b * V);
-    for (int v = 0; v < nv; ++v) {
-        float acc = 0.f;
+    float xo[FN];
+    irfft64(yr, yi, xo);
 #pragma unroll
-        for (int f = 1; f < FF; ++f) {
-            const float2 t = tw[(f * v) & (FN - 1)];
-            acc = fmaf(yr[f], t.x, acc);
-            acc = fmaf(-yi[f], t.y, acc);
-        }
-        const float r = yr[0] + ((v & 1) ? -yi[0] : yi[0]) + 2.0f * acc;
-        row[v] = r * (1.0f / FN);
-    }
+    for (int v = 0; v < FN - 12; ++v)      // V <= 52 (kw >= 13)
+        if (v < nv) row[v] = xo[v];
 }
 
 // z [nb, C, H, T] (raw conv output, no bias) -> y = dropout(relu(maxpool(z) + bias)), arg-max rows
@@ -168,60 +143,69 @@ __global__ void mask_unpool_kernel(const float* __restrict__ dxraw, const float*
 
 // Frequency weights in conv_core's slab order for the real-embedded operator (CIN_c = 2*cin_c, COUT_c = 2*cout_c,
 // 1 x kh taps):  [branch*FF + f][cob][cc][cp][tap][wm][lane_h][i][m].
-__global__ void pack_freq_weights_kernel(Ptr2 w, float* __restrict__ dst, int cin_c, int cout_c, int kh, int kw,
-                                         int cob_sz, int ck, int mt, int wm_n, int transposed, long long per_wf,
-                                         int nbr) {
-    const long long total = per_wf * FF * nbr;
-    const int CI2 = 2 * cin_c;
-    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total;
-         o += (long long)gridDim.x * blockDim.x) {
-        const int widx = (int)(o / per_wf);
-        const int br = widx / FF, f = widx % FF;
-        long long q = o % per_wf;
-        const int m = (int)(q % mt); q /= mt;
-        const int i = (int)(q % 32); q /= 32;
-        const int h = (int)(q % 2); q /= 2;
-        const int wm = (int)(q % wm_n); q /= wm_n;
-        const int tap = (int)(q % kh); q /= kh;
-        const int cp = (int)(q % (ck / 2)); q /= (ck / 2);
-        const int ncc = CI2 / ck;
-        const int cc = (int)(q % ncc); q /= ncc;
-        const int cob = (int)q;
-        const int cop = cob * cob_sz + (wm * mt + m) * 32 + i;   // real-embedded output channel
-        const int cip = cc * ck + 2 * cp + h;                     // real-embedded input channel
-        const int co = cop >> 1, a = cop & 1, ci = cip >> 1, c = cip & 1;
-        // taps along time of the (co, ci, tap) kernel row, as the core sees them
-        const float* wr;
-        int sstep;
-        if (!transposed) {
-            wr = w.p[br] + (((size_t)co * cin_c + ci) * kh + tap) * kw;                     // W[co][ci][tap][s]
-            sstep = 1;
-        } else {
-            // original tensor [cout_o = cin_c][cin_o = cout_c][kh][kw]; flipped in both kernel axes
-            wr = w.p[br] + (((size_t)ci * cout_c + co) * kh + (kh - 1 - tap)) * kw + (kw - 1);
-            sstep = -1;
+// One thread owns one complex entry G(co, ci, tap) -- i.e. the 2x2 real block [[gr, -gi], [gi, gr]] that sits at
+// (lane_h, i) in {0,1} x {2*ih, 2*ih+1} of the slab -- reads its kw time taps once and loops over the 32 frequency
+// slots, so the weights are read once and every slab is written with coalesced stores.
+__global__ void __launch_bounds__(256) pack_freq_weights_kernel(Ptr2 w, float* __restrict__ dst, int cin_c, int cout_c,
+                                                                int kh, int kw, int cob_sz, int ck, int mt, int wm_n,
+                                                                int transposed, long long per_wf, int nbr) {
+    __shared__ float2 tw[FN];
+    twiddle_init(tw);
+    __syncthreads();
+    const long long quads = per_wf / 4;
+    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= quads * nbr) return;
+    const int br = (int)(o / quads);
+    long long q = o % quads;
+    const int m = (int)(q % mt); q /= mt;
+    const int ih = (int)(q % 16); q /= 16;
+    const int wm = (int)(q % wm_n); q /= wm_n;
+    const int tap = (int)(q % kh); q /= kh;
+    const int cp = (int)(q % (ck / 2)); q /= (ck / 2);
+    const int ncc = 2 * cin_c / ck;
+    const int cc = (int)(q % ncc); q /= ncc;
+    const int cob = (int)q;
+    const int co = (cob * cob_sz + (wm * mt + m) * 32 + 2 * ih) >> 1;   // complex output channel
+    const int ci = ((cc * ck) >> 1) + cp;                                // complex input channel
+    // slab offset of the (lane_h = 0, i = 2*ih) entry; i + 1 is mt floats further, lane_h = 1 is 32*mt further
+    const long long off = ((((((long long)cob * ncc + cc) * (ck / 2) + cp) * kh + tap) * wm_n + wm) * 64 + 2 * ih) * mt + m;
+    float wt[25];
+    if (!transposed) {
+        const float* wr = w.p[br] + (((size_t)co * cin_c + ci) * kh + tap) * kw;                     // W[co][ci][tap][s]
+#pragma unroll
+        for (int s = 0; s < 25; ++s) wt[s] = s < kw ? wr[s] : 0.f;
+    } else {
+        // original tensor [cout_o = cin_c][cin_o = cout_c][kh][kw]; flipped in both kernel axes
+        const float* wr = w.p[br] + (((size_t)ci * cout_c + co) * kh + (kh - 1 - tap)) * kw;
+#pragma unroll
+        for (int s = 0; s < 25; ++s) wt[s] = s < kw ? wr[kw - 1 - s] : 0.f;
+    }
+    float* d = dst + (size_t)br * FF * per_wf + off;
+    {
+        float g0 = 0.f, g32 = 0.f;
+#pragma unroll
+        for (int s = 0; s < 25; ++s) {   // taps beyond kw are zero
+            g0 += wt[s];
+            g32 += (s & 1) ? -wt[s] : wt[s];
         }
-        float v;
-        if (f == 0) {
-            float g0 = 0.f, g32 = 0.f;
-            for (int s = 0; s < kw; ++s) {
-                const float ws = wr[s * sstep];
-                g0 += ws;
-                g32 += (s & 1) ? -ws : ws;
-            }
-            v = (a == 0 && c == 0) ? g0 : ((a == 1 && c == 1) ? g32 : 0.f);
-        } else {
-            float gr = 0.f, gi = 0.f;
-            for (int s = 0; s < kw; ++s) {
-                float sn, cs;
-                sincospif((float)((f * s) & (FN - 1)) / 32.0f, &sn, &cs);
-                const float ws = wr[s * sstep];
-                gr = fmaf(ws, cs, gr);
-                gi = fmaf(ws, sn, gi);
-            }
-            v = (a == c) ? gr : (a == 1 ? gi : -gi);
+        d[0] = g0;                 // (re <- re)
+        d[mt] = 0.f;               // (im <- re)
+        d[32 * mt] = 0.f;          // (re <- im)
+        d[32 * mt + mt] = g32;     // (im <- im): Nyquist
+    }
+    for (int f = 1; f < FF; ++f) {
+        float gr = 0.f, gi = 0.f;
+#pragma unroll
+        for (int s = 0; s < 25; ++s) {
+            const float2 t = tw[(f * s) & (FN - 1)];
+            gr = fmaf(wt[s], t.x, gr);
+            gi = fmaf(wt[s], t.y, gi);
         }
-        dst[o] = v;
+        float* df = d + (size_t)f * per_wf;
+        df[0] = gr;
+        df[mt] = gi;
+        df[32 * mt] = -gi;
+        df[32 * mt + mt] = gr;
     }
 }
 
@@ -273,8 +257,8 @@ __global__ void wgrad_spec_reduce_kernel(const float* __restrict__ slab, MPtr2 d
 // =====================================================================================================
 //                  CIN' COUT' KH KW(taps) H  MT RT CT WM WR WC CK POOL EPI DILMAX
 using FF2 = ConvCfg<128, 128, 1, 7, 1, 4, 1, 2, 1, 1, 4, 8, 1, 1, FDIL>;
-using FF3 = ConvCfg<128, 256, 1, 5, 1, 4, 1, 2, 2, 1, 2, 8, 1, 1, FDIL>;
-using FF4 = ConvCfg<256, 256, 1, 9, 1, 4, 1, 2, 2, 1, 2, 4, 1, 1, FDIL>;
+using FF3 = ConvCfg<128, 256, 1, 5, 1, 4, 1, 1, 2, 1, 4, 8, 1, 1, FDIL>;
+using FF4 = ConvCfg<256, 256, 1, 9, 1, 4, 1, 1, 2, 1, 4, 4, 1, 1, FDIL>;
 using FF5 = ConvCfg<256, 512, 1, 3, 1, 4, 1, 1, 2, 1, 3, 16, 1, 1, FDIL>;
 using FF6 = ConvCfg<512, 512, 1, 5, 1, 4, 1, 1, 2, 1, 3, 8, 1, 1, FDIL>;
 using FD2 = FF2;
@@ -408,8 +392,8 @@ static int run_fconv(const ConvArgs& a, const FftGeom& g, Ptr2 w, int transposed
     // pack: the core's CIN/COUT are the real-embedded channel counts
     const int cin_c = C::CIN / 2, cout_c = C::COUT / 2;
     const long long per_wf = (long long)C::COUT * C::CIN * C::KW;
-    const long long total = per_wf * FF * a.nbr;
-    const int blocks = (int)((total + 255) / 256 > 16384 ? 16384 : (total + 255) / 256);
+    const long long total = per_wf / 4 * a.nbr;
+    const int blocks = (int)((total + 255) / 256);
     hipLaunchKernelGGL(pack_freq_weights_kernel, dim3(blocks), dim3(256), 0, st, w, wf, cin_c, cout_c, C::KW, a.kw,
                        C::COB, C::CK, C::MT, C::WM, transposed, per_wf, a.nbr);
     ZNS_LAUNCH_CHECK();
