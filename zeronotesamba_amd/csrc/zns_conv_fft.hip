@@ -64,79 +64,108 @@ __global__ void __launch_bounds__(256) spec_fwd_kernel(const float* __restrict__
     }
 }
 
-// S [nb][FF][2C][P] -> z [nb, C, H, T]: 64-point inverse real DFT of each window, first V samples kept.
-__global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__ S, float* __restrict__ z, int C, int H,
-                                                       int T, int V, int NB, int chunks) {
-    const int P = H * NB;
+// S [nb][FF][2C][P] -> inverse 64-point real FFT of each window, first V samples kept, with the layer epilogue fused:
+//   MODE 0  z  = raw conv output                                         (plain store)
+//   MODE 1  y  = dropout(relu(maxpool_rows(z) + bias)), arg-max rows     (forward: thread owns `pool` rows of a window)
+//   MODE 2  dx = max-unpool(mask(z))                                      (backward-data epilogue, see zns.h)
+struct InvEpi {
+    Ptr2 bias;                 // MODE 1
+    uint8_t* argmax;
+    int pool, B;
+    uint32_t thresh, seed;
+    int layer;
+    float inv_keep;            // MODE 1 and 2
+    const float* xmask;        // MODE 2
+    const uint8_t* prev_argmax;
+    int prev_pool;
+};
+
+constexpr int IVMAX = FN - 12;     // V <= 52 (kw >= 13)
+constexpr int IVS = IVMAX + 1;     // odd LDS stride: the per-lane rows of the staging tile hit distinct banks
+
+template <int MODE>
+__global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__ S, float* __restrict__ out, int C, int H,
+                                                       int T, int V, int NB, int chunks, InvEpi E) {
+    __shared__ float stage[256 * IVS];
+    __shared__ uint8_t stage_am[MODE == 1 ? 256 * IVMAX : 4];
+    const int pool = MODE == 1 ? E.pool : 1;
+    const int Hq = H / pool;                       // output rows per plane (pooled rows in MODE 1)
+    const int Pq = Hq * NB;
     const int chunk = blockIdx.x % chunks;
     const int plane = blockIdx.x / chunks;
     const int c = plane % C, n = plane / C;
-    const int p = chunk * 256 + threadIdx.x;
-    if (p >= P) return;
-    const int h = p / NB, b = p - h * NB;
-    const float* in = S + (((size_t)n * FF) * 2 * C + 2 * c) * P + p;
+    const int pq = chunk * 256 + threadIdx.x;
+    const bool active = pq < Pq;
+    const int P = H * NB;
     const size_t fstride = (size_t)2 * C * P;
-    float yr[FF], yi[FF];
+    if (active) {
+        const int hq = pq / NB, b = pq - hq * NB;
+        float best[IVMAX];
+        int am[(IVMAX + 3) / 4];
 #pragma unroll
-    for (int f = 0; f < FF; ++f) {
-        yr[f] = in[f * fstride];
-        yi[f] = in[f * fstride + P];
-    }
-    float* row = z + ((size_t)plane * H + h) * T + b * V;
-    const int nv = min(V, T - b * V);
-    float xo[FN];
-    irfft64(yr, yi, xo);
+        for (int i = 0; i < (IVMAX + 3) / 4; ++i) am[i] = 0;
+        for (int a = 0; a < pool; ++a) {
+            const int h = hq * pool + a;
+            const float* in = S + (((size_t)n * FF) * 2 * C + 2 * c) * P + (size_t)h * NB + b;
+            float yr[FF], yi[FF];
 #pragma unroll
-    for (int v = 0; v < FN - 12; ++v)      // V <= 52 (kw >= 13)
-        if (v < nv) row[v] = xo[v];
-}
-
-// z [nb, C, H, T] (raw conv output, no bias) -> y = dropout(relu(maxpool(z) + bias)), arg-max rows
-__global__ void pool_relu_drop_kernel(const float* __restrict__ z, Ptr2 bias, float* __restrict__ y,
-                                      uint8_t* __restrict__ argmax, int B, int C, int H, int T, int pool,
-                                      uint32_t thresh, float inv_keep, uint32_t seed, int layer, long long total) {
-    const int Hp = H / pool;
-    const long long per_branch = (long long)B * C * Hp * T;
-    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total;
-         o += (long long)gridDim.x * blockDim.x) {
-        const int t = (int)(o % T);
-        long long q = o / T;
-        const int hp = (int)(q % Hp);
-        q /= Hp;
-        const int co = (int)(q % C);
-        const int n = (int)(q / C);
-        const int br = n / B;
-        const float* zp = z + (((size_t)n * C + co) * H + (size_t)hp * pool) * T + t;
-        float best = zp[0];
-        int am = 0;
-        for (int a = 1; a < pool; ++a) {
-            const float v = zp[(size_t)a * T];
-            if (v > best) { best = v; am = a; }
+            for (int f = 0; f < FF; ++f) {
+                yr[f] = in[f * fstride];
+                yi[f] = in[f * fstride + P];
+            }
+            float xo[FN];
+            irfft64(yr, yi, xo);
+#pragma unroll
+            for (int v = 0; v < IVMAX; ++v) {
+                if (a == 0 || xo[v] > best[v]) {       // first maximum wins, as ATen's max_pool2d
+                    best[v] = xo[v];
+                    if (MODE == 1 && a) am[v >> 2] = (am[v >> 2] & ~(0xff << ((v & 3) * 8))) | (a << ((v & 3) * 8));
+                }
+            }
         }
-        float v = best + bias.p[br][co];
-        v = v > 0.f ? v : 0.f;
-        if (thresh) v = drop_keep(layer_seed(seed, layer, br), (uint64_t)(o - (long long)br * per_branch), thresh) ? v * inv_keep : 0.f;
-        y[o] = v;
-        if (argmax && pool > 1) argmax[o] = (uint8_t)am;
+#pragma unroll
+        for (int v = 0; v < IVMAX; ++v) {
+            stage[threadIdx.x * IVS + v] = best[v];
+            if (MODE == 1) stage_am[threadIdx.x * IVMAX + v] = (uint8_t)((am[v >> 2] >> ((v & 3) * 8)) & 0xff);
+        }
     }
-}
-
-// dxraw [nb, C, H, T] -> dx: ReLU/dropout mask of the previous layer's output x, then max-unpool through its arg-max
-__global__ void mask_unpool_kernel(const float* __restrict__ dxraw, const float* __restrict__ x, float inv_keep,
-                                   const uint8_t* __restrict__ prev_argmax, int pp, float* __restrict__ dx, int T,
-                                   long long total) {
-    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total;
-         o += (long long)gridDim.x * blockDim.x) {
-        float g = dxraw[o];
-        if (x) g = (x[o] != 0.f) ? g * inv_keep : 0.f;
-        if (pp > 1) {
-            const int am = prev_argmax[o];
-            const long long rowi = o / T;
-            const int t = (int)(o - rowi * T);
-            float* d = dx + (size_t)rowi * pp * T + t;
-            for (int a = 0; a < pp; ++a) d[(size_t)a * T] = (a == am) ? g : 0.f;
+    __syncthreads();
+    // coalesced epilogue: the block's 256 windows are consecutive in (row, window) order, i.e. (almost) one contiguous
+    // run of the output; element e of the block = window e / V, sample e % V.
+    const int p0 = chunk * 256;
+    const int nwin = min(256, Pq - p0);
+    const int br = n / (MODE == 1 ? E.B : 1), bb = n - br * (MODE == 1 ? E.B : 1);
+    const float bv = MODE == 1 ? E.bias.p[br][c] : 0.f;
+    const uint32_t lseed = MODE == 1 ? layer_seed(E.seed, E.layer, br) : 0u;
+    for (int e = threadIdx.x; e < nwin * V; e += 256) {
+        const int w = e / V, v = e - w * V;
+        const int p = p0 + w;
+        const int hq = p / NB, b = p - hq * NB;
+        const int col = b * V + v;
+        if (col >= T) continue;
+        float r = stage[w * IVS + v];
+        const size_t o = ((size_t)plane * Hq + hq) * T + col;
+        if (MODE == 0) {
+            out[o] = r;
+        } else if (MODE == 1) {
+            r += bv;
+            r = r > 0.f ? r : 0.f;
+            if (E.thresh) {
+                const uint64_t idx = (((uint64_t)bb * C + c) * Hq + hq) * T + col;
+                r = drop_keep(lseed, idx, E.thresh) ? r * E.inv_keep : 0.f;
+            }
+            out[o] = r;
+            if (E.argmax && pool > 1) E.argmax[o] = stage_am[w * IVMAX + v];
         } else {
-            dx[o] = g;
+            if (E.xmask) r = (E.xmask[o] != 0.f) ? r * E.inv_keep : 0.f;
+            const int pp = E.prev_pool;
+            if (pp > 1) {
+                const int amx = E.prev_argmax[o];
+                float* d = out + (((size_t)plane * Hq + hq) * pp) * T + col;
+                for (int q = 0; q < pp; ++q) d[(size_t)q * T] = (q == amx) ? r : 0.f;
+            } else {
+                out[o] = r;
+            }
         }
     }
 }
@@ -252,6 +281,27 @@ __global__ void wgrad_spec_reduce_kernel(const float* __restrict__ slab, MPtr2 d
     }
 }
 
+// bias gradient from the spectrum of the zero-padded dZ blocks: slot 0 "re" is each block's sum
+__global__ void __launch_bounds__(256) spec_dc_sum_kernel(const float* __restrict__ sz, MPtr2 db, int B, int C, int P,
+                                                          int accumulate) {
+    __shared__ float red[4];
+    const int co = blockIdx.x % C, br = blockIdx.x / C;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* sp = sz + (((size_t)(br * B + b) * FF) * 2 * C + 2 * co) * P;
+        for (int p = threadIdx.x; p < P; p += 256) acc += sp[p];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float s = red[0] + red[1] + red[2] + red[3];
+        float* d = db.p[br] + co;
+        *d = accumulate ? *d + s : s;
+    }
+}
+
 // =====================================================================================================
 //                                          instances + dispatch
 // =====================================================================================================
@@ -358,10 +408,13 @@ static int run_spec_fwd(const float* x, float* S, int nb, int C, int H, int T, c
     return ZNS_OK;
 }
 
-static int run_spec_inv(const float* S, float* z, int nb, int C, int H, int T, const FftGeom& g, hipStream_t st) {
-    const int chunks = ceil_div(g.P, 256);
-    hipLaunchKernelGGL(spec_inv_kernel, dim3((unsigned)((size_t)nb * C * chunks)), dim3(256), 0, st, S, z, C, H, T, g.V,
-                       g.NB, chunks);
+template <int MODE>
+static int run_spec_inv(const float* S, float* out, int nb, int C, int H, int T, const FftGeom& g, const InvEpi& E,
+                        hipStream_t st) {
+    const int pool = MODE == 1 ? E.pool : 1;
+    const int chunks = ceil_div((H / pool) * g.NB, 256);
+    hipLaunchKernelGGL(spec_inv_kernel<MODE>, dim3((unsigned)((size_t)nb * C * chunks)), dim3(256), 0, st, S, out, C, H, T,
+                       g.V, g.NB, chunks, E);
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
 }
@@ -437,16 +490,17 @@ static int fft_fwd_t(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float
     if (rc) return rc;
     rc = run_fconv<C>(a, g, w, 0, s_in, s_out, wf, 0, st);
     if (rc) return rc;
-    rc = run_spec_inv(s_out, z, g.nb, a.cout, a.H, a.T, g, st);
-    if (rc) return rc;
-    const long long total = (long long)g.nb * a.cout * (a.H / a.pool) * a.T;
-    const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
-    const uint32_t thresh = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
-    const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
-    hipLaunchKernelGGL(pool_relu_drop_kernel, dim3(blocks), dim3(256), 0, st, z, bias, y, argmax, a.B, a.cout, a.H, a.T,
-                       a.pool, thresh, inv_keep, seed, layer, total);
-    ZNS_LAUNCH_CHECK();
-    return ZNS_OK;
+    InvEpi E{};
+    E.bias = bias;
+    E.argmax = argmax;
+    E.pool = a.pool;
+    E.B = a.B;
+    E.thresh = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
+    E.inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
+    E.seed = seed;
+    E.layer = layer;
+    (void)z;
+    return run_spec_inv<1>(s_out, y, g.nb, a.cout, a.H, a.T, g, E, st);
 }
 
 template <class C>
@@ -464,19 +518,17 @@ static int fft_dgrad_t(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, co
     if (rc) return rc;
     rc = run_fconv<C>(a, g, w, 1, s_in, s_out, wf, 1, st);
     if (rc) return rc;
-    const bool plain = (x == nullptr && prev_pool == 1);
-    rc = run_spec_inv(s_out, plain ? dx : z, g.nb, a.cin, a.H, a.T, g, st);
-    if (rc || plain) return rc;
-    const long long total = (long long)g.nb * a.cin * a.H * a.T;
-    const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
-    hipLaunchKernelGGL(mask_unpool_kernel, dim3(blocks), dim3(256), 0, st, z, x, inv_keep, prev_argmax, prev_pool, dx,
-                       a.T, total);
-    ZNS_LAUNCH_CHECK();
-    return ZNS_OK;
+    InvEpi E{};
+    E.xmask = x;
+    E.inv_keep = inv_keep;
+    E.prev_argmax = prev_argmax;
+    E.prev_pool = prev_pool;
+    (void)z;
+    return run_spec_inv<2>(s_out, dx, g.nb, a.cin, a.H, a.T, g, E, st);
 }
 
 template <class W>
-static int fft_wgrad_t(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, int accumulate, void* ws,
+static int fft_wgrad_t(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, MPtr2 db, int accumulate, void* ws,
                        size_t ws_bytes, hipStream_t st) {
     const FftGeom g = geom(a);
     const FftWs L = fft_ws(a);
@@ -489,6 +541,9 @@ static int fft_wgrad_t(const ConvArgs& a, const float* dz, const float* x, MPtr2
     if (rc) return rc;
     rc = run_spec_fwd(dz, sz, g.nb, a.cout, a.H, a.T, g, 0, g.V, st);           // zero-padded V-blocks of dZ
     if (rc) return rc;
+    hipLaunchKernelGGL(spec_dc_sum_kernel, dim3(a.nbr * a.cout), dim3(256), 0, st, (const float*)sz, db, a.B, a.cout,
+                       g.P, accumulate);
+    ZNS_LAUNCH_CHECK();
     rc = set_lds_fw<W>(wgrad_core<W>);
     if (rc) return rc;
     WgArgs A{};
@@ -540,14 +595,14 @@ int fft_dgrad(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, const float
     return ZNS_ERR_ARG;
 }
 
-int fft_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, int accumulate, void* ws, size_t ws_bytes,
-              hipStream_t st) {
+int fft_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, MPtr2 db, int accumulate, void* ws,
+              size_t ws_bytes, hipStream_t st) {
     switch (fft_layer_of(a)) {
-        case 2: return fft_wgrad_t<FW2>(a, dz, x, dw, accumulate, ws, ws_bytes, st);
-        case 3: return fft_wgrad_t<FW3>(a, dz, x, dw, accumulate, ws, ws_bytes, st);
-        case 4: return fft_wgrad_t<FW4>(a, dz, x, dw, accumulate, ws, ws_bytes, st);
-        case 5: return fft_wgrad_t<FW5>(a, dz, x, dw, accumulate, ws, ws_bytes, st);
-        case 6: return fft_wgrad_t<FW6>(a, dz, x, dw, accumulate, ws, ws_bytes, st);
+        case 2: return fft_wgrad_t<FW2>(a, dz, x, dw, db, accumulate, ws, ws_bytes, st);
+        case 3: return fft_wgrad_t<FW3>(a, dz, x, dw, db, accumulate, ws, ws_bytes, st);
+        case 4: return fft_wgrad_t<FW4>(a, dz, x, dw, db, accumulate, ws, ws_bytes, st);
+        case 5: return fft_wgrad_t<FW5>(a, dz, x, dw, db, accumulate, ws, ws_bytes, st);
+        case 6: return fft_wgrad_t<FW6>(a, dz, x, dw, db, accumulate, ws, ws_bytes, st);
     }
     return ZNS_ERR_ARG;
 }
