@@ -341,7 +341,7 @@ struct WgArgs {
 template <class C>
 __device__ __forceinline__ void wg_load_tile(const WgArgs& A, int br, int cob, int cit, int r0, int tile, float* zb,
                                              float* xb, int wid, int lane, const int (&xrel)[C::NXI],
-                                             const int (&xrc)[C::NXI]) {
+                                             const int (&xrc)[C::NXI], int pcw, int nxq) {
     const int T = A.T;
     const int cbk = tile % A.ncb;
     const int h0 = (tile / A.ncb) % C::H;
@@ -366,12 +366,12 @@ __device__ __forceinline__ void wg_load_tile(const WgArgs& A, int br, int cob, i
         }
     }
     const int hbase = h0 + r0 - C::PH, wbase = w0 - (C::DILMAX ? (C::KW / 2) * A.dil : C::PW);
-    const bool interior = hbase >= 0 && hbase + C::PRW <= C::H && wbase >= 0 && wbase + C::PCW <= T;
+    const bool interior = hbase >= 0 && hbase + C::PRW <= C::H && wbase >= 0 && wbase + pcw <= T;
     const float* xbase = A.x + ((size_t)n * C::CIN + (size_t)cit * 32) * C::H * T + (ptrdiff_t)hbase * T + wbase;
 #pragma unroll
     for (int i = 0; i < C::NXI; ++i) {
         const int q = wid + i * C::NW;
-        if (q < C::XBUF / 64) {
+        if (q < nxq) {
             bool ok = xrel[i] >= 0;
             if (!interior) {
                 const int hh = hbase + (xrc[i] >> 16), ww = wbase + (xrc[i] & 0xffff);
@@ -415,15 +415,20 @@ __global__ void __launch_bounds__(C::NT) wgrad_core(WgArgs A) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[m][s][k] = 0.f;
 
+    // X-patch geometry: in the frequency-domain use the row width follows the runtime tap spacing, so only the
+    // columns that are read get staged (the LDS buffer is sized for DILMAX)
+    const int pcw = C::DILMAX ? C::CW + (C::KW - 1) * A.dil : C::PCW;
+    const int ps = C::DILMAX ? ((C::PRW * pcw) | 1) : C::PS;
+    const int nxq = C::DILMAX ? (32 * ps + 63) / 64 : C::XBUF / 64;
     // X-patch DMA source offsets of this wave (tile independent)
     int xrel[C::NXI], xrc[C::NXI];
 #pragma unroll
     for (int i = 0; i < C::NXI; ++i) {
         const int L = (wid + i * C::NW) * 64 + lane;
-        const int ci = L / C::PS;
-        const int rem = L - ci * C::PS;
-        const int row = rem / C::PCW;
-        const int col = rem - row * C::PCW;
+        const int ci = L / ps;
+        const int rem = L - ci * ps;
+        const int row = rem / pcw;
+        const int col = rem - row * pcw;
         const bool ok = ci < 32 && row < C::PRW;
         xrel[i] = ok ? (ci * C::H + row) * A.T + col : -1;
         xrc[i] = (row << 16) | col;
@@ -439,16 +444,16 @@ __global__ void __launch_bounds__(C::NT) wgrad_core(WgArgs A) {
         int q = q0 + wq * C::NS + s;
         if (q >= C::Q) q = C::Q - 1;   // padded shift: computed, never stored
         const int rr = q / C::KW, ss = q - rr * C::KW;
-        xoff[s] = lane_j * C::PS + (rr - r0) * C::PCW + (C::DILMAX ? ss * A.dil : ss) + 4 * lane_h;
+        xoff[s] = lane_j * ps + (rr - r0) * pcw + (C::DILMAX ? ss * A.dil : ss) + 4 * lane_h;
     }
 
-    if (t_begin < t_end) wg_load_tile<C>(A, br, cob, cit, r0, t_begin, zbuf(0), xbuf(0), wid, lane, xrel, xrc);
+    if (t_begin < t_end) wg_load_tile<C>(A, br, cob, cit, r0, t_begin, zbuf(0), xbuf(0), wid, lane, xrel, xrc, pcw, nxq);
     int cur = 0;
     for (int tile = t_begin; tile < t_end; ++tile, cur ^= 1) {
         wait_vm0();
         __syncthreads();
         if (tile + 1 < t_end)
-            wg_load_tile<C>(A, br, cob, cit, r0, tile + 1, zbuf(cur ^ 1), xbuf(cur ^ 1), wid, lane, xrel, xrc);
+            wg_load_tile<C>(A, br, cob, cit, r0, tile + 1, zbuf(cur ^ 1), xbuf(cur ^ 1), wid, lane, xrel, xrc, pcw, nxq);
         const float* __restrict__ zp = zbuf(cur) + zrowbase;
         const float* __restrict__ xp = xbuf(cur);
 #pragma unroll

@@ -119,21 +119,23 @@ __global__ void __launch_bounds__(128) cv1_wgrad_kernel(int T, int H, const floa
     }
 }
 
-// thread -> (br, co, k): sums the B*H partials of that channel in a fixed order (deterministic)
-__global__ void cv1_wgrad_reduce(int B, int H, const float* __restrict__ part, MPtr2 dw, MPtr2 db, int accumulate,
-                                 int nbr) {
+// wave -> (br, co, k): sums the B*H partials of that tap in a fixed lane/tree order (deterministic)
+__global__ void __launch_bounds__(64) cv1_wgrad_reduce(int B, int H, const float* __restrict__ part, MPtr2 dw, MPtr2 db,
+                                                       int accumulate, int nbr) {
     constexpr int K1 = CV1_KH * CV1_KW + 1;
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= nbr * CV1_CO * K1) return;
+    const int o = blockIdx.x;
     const int k = o % K1, co = (o / K1) % CV1_CO, br = o / (K1 * CV1_CO);
     float s = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const int n = br * B + b;
-        const float* pp = part + ((size_t)(n * CV1_CO + co) * H) * K1 + k;
-        for (int h = 0; h < H; ++h) s += pp[(size_t)h * K1];
+    for (int i = threadIdx.x; i < B * H; i += 64) {
+        const int b = i / H, h = i - b * H;
+        s += part[((size_t)((br * B + b) * CV1_CO + co) * H + h) * K1 + k];
     }
-    float* d = (k < K1 - 1) ? dw.p[br] + co * (K1 - 1) + k : db.p[br] + co;
-    *d = accumulate ? *d + s : s;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (threadIdx.x == 0) {
+        float* d = (k < K1 - 1) ? dw.p[br] + co * (K1 - 1) + k : db.p[br] + co;
+        *d = accumulate ? *d + s : s;
+    }
 }
 
 size_t cv1_workspace_bytes(const ConvArgs& a) {
@@ -162,7 +164,7 @@ int cv1_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, MPtr
     hipLaunchKernelGGL(cv1_wgrad_kernel, dim3(a.nbr * a.B * CV1_CO * a.H), dim3(128), 0, st, a.T, a.H, dz, x, part);
     ZNS_LAUNCH_CHECK();
     const int n = a.nbr * CV1_CO * (CV1_KH * CV1_KW + 1);
-    hipLaunchKernelGGL(cv1_wgrad_reduce, dim3((n + 127) / 128), dim3(128), 0, st, a.B, a.H, part, dw, db, accumulate,
+    hipLaunchKernelGGL(cv1_wgrad_reduce, dim3(n), dim3(64), 0, st, a.B, a.H, part, dw, db, accumulate,
                        a.nbr);
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
