@@ -80,20 +80,39 @@ struct CoreArgs {
     int prev_pool;
 };
 
+// Input patch [CK][PR][PCW] (+pad) of the workgroup's tile.  The tile is fixed for the whole kernel, so each wave
+// computes the per-lane source offsets of ITS DMA instructions once (patch_offsets: -1 = outside the image or the
+// padding -> zero page); staging a ci-chunk is then one add + select per instruction.
 template <class C>
-__device__ __forceinline__ void load_patch(const float* xn, int cc, int h0, int w0, int T, float* lds_patch, int wid,
-                                           int lane, int pw = C::PW) {
-    constexpr int NI = C::PATCH / 64;
-    for (int q = wid; q < NI; q += C::NW) {
-        const int L = q * 64 + lane;
+struct PatchPlan {
+    static constexpr int NPI = (C::PATCH / 64 + C::NW - 1) / C::NW;
+    int rel[NPI];
+};
+
+template <class C>
+__device__ __forceinline__ void patch_offsets(PatchPlan<C>& pl, int h0, int w0, int T, int wid, int lane, int pw,
+                                              int live_cols) {
+#pragma unroll
+    for (int i = 0; i < PatchPlan<C>::NPI; ++i) {
+        const int L = (wid + i * C::NW) * 64 + lane;
         const int ci = L / C::PS;
         const int rem = L - ci * C::PS;
         const int row = rem / C::PCW;
         const int col = rem - row * C::PCW;
         const int hh = h0 - C::PH + row, ww = w0 - pw + col;
-        const bool ok = (ci < C::CK) && (row < C::PR) && hh >= 0 && hh < C::H && ww >= 0 && ww < T;
-        const float* src = ok ? xn + ((size_t)(cc * C::CK + ci) * C::H + hh) * T + ww : g_zero_page;
-        glds4(src, lds_patch + q * 64);
+        const bool ok = (ci < C::CK) && (row < C::PR) && (col < live_cols) && hh >= 0 && hh < C::H && ww >= 0 && ww < T;
+        pl.rel[i] = ok ? (ci * C::H + hh) * T + ww : -1;
+    }
+}
+
+template <class C>
+__device__ __forceinline__ void load_patch(const PatchPlan<C>& pl, const float* xn, int cc, int T, float* lds_patch,
+                                           int wid) {
+    const float* base = xn + (size_t)cc * C::CK * C::H * T;
+#pragma unroll
+    for (int i = 0; i < PatchPlan<C>::NPI; ++i) {
+        const int q = wid + i * C::NW;
+        if (q < C::PATCH / 64) glds4(pl.rel[i] >= 0 ? base + pl.rel[i] : g_zero_page, lds_patch + q * 64);
     }
 }
 
@@ -180,7 +199,9 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
     const int abase = wm * (64 * C::MT) + lane * C::MT;
     const int bbase = lane_h * C::PS + (wr * C::RT) * C::PCW + wc * C::CT * 32 + lane_j;
 
-    load_patch<C>(xn, 0, h0, w0, T, patch(0), wid, lane, pw);
+    PatchPlan<C> plan;
+    patch_offsets<C>(plan, h0, w0, T, wid, lane, pw, C::DILMAX ? C::WB + (C::KW - 1) * dil : C::PCW);
+    load_patch<C>(plan, xn, 0, T, patch(0), wid);
     load_slab<C>(wbase, slab(0), wid, lane);
 
     int st = 0;
@@ -190,7 +211,7 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
             __syncthreads();
             if (st + 1 < C::NST) {
                 load_slab<C>(wbase + (size_t)(st + 1) * C::SLAB, slab(st + 1), wid, lane);
-                if (r == C::KH - 1) load_patch<C>(xn, cc + 1, h0, w0, T, patch(cc + 1), wid, lane, pw);
+                if (r == C::KH - 1) load_patch<C>(plan, xn, cc + 1, T, patch(cc + 1), wid);
             }
             compute_stage<C>(slab(st) + abase, patch(cc) + bbase + r * C::PCW, acc, dil);
         }

@@ -312,7 +312,7 @@ using FF4 = ConvCfg<256, 256, 1, 9, 1, 4, 1, 1, 2, 1, 4, 4, 1, 1, FDIL>;
 using FF5 = ConvCfg<256, 512, 1, 3, 1, 4, 1, 1, 2, 1, 3, 16, 1, 1, FDIL>;
 using FF6 = ConvCfg<512, 512, 1, 5, 1, 4, 1, 1, 2, 1, 3, 8, 1, 1, FDIL>;
 using FD2 = FF2;
-using FD3 = ConvCfg<256, 128, 1, 5, 1, 4, 1, 2, 1, 1, 3, 8, 1, 1, FDIL>;
+using FD3 = ConvCfg<256, 128, 1, 5, 1, 4, 1, 1, 1, 1, 4, 8, 1, 1, FDIL>;
 using FD4 = FF4;
 using FD5 = ConvCfg<512, 256, 1, 3, 1, 4, 1, 1, 2, 1, 3, 16, 1, 1, FDIL>;
 using FD6 = FF6;
