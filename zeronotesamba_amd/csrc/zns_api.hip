@@ -116,7 +116,7 @@ int zns_conv2d_wgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int k
         return channel_sum(nbr, B, cout, (long long)H * T, dz, pdb, accumulate, st);
     }
     if (is_cv1(a)) return cv1_wgrad(a, dz, x, pdw, pdb, accumulate, ws, ws_bytes, st);
-    if (g_impl == ZNS_IMPL_AUTO && fft_supported(a))
+    if (g_impl == ZNS_IMPL_AUTO && fft_wgrad_supported(a))
         return fft_wgrad(a, dz, x, pdw, pdb, accumulate, ws, ws_bytes, st);
     if (mfma_supported(a)) {
         rc = mfma_wgrad(a, dz, x, pdw, accumulate, ws, ws_bytes, st);

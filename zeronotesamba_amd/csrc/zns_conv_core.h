@@ -323,13 +323,16 @@ static __global__ void pack_weights_kernel(Ptr2 w, float* __restrict__ dst, int 
 // =====================================================================================================
 //                                        backward-weights core
 // =====================================================================================================
-template <int CIN_, int COUT_, int KH_, int KW_, int H_, int MT_, int NS_, int WMW_, int WQ_, int R_, int DILMAX_ = 0>
+template <int CIN_, int COUT_, int KH_, int KW_, int H_, int MT_, int NS_, int WMW_, int WQ_, int R_, int DILMAX_ = 0,
+          int WCI_ = 1>
 struct WgCfg {
+    static constexpr int WCI = WCI_;         // 32-channel input tiles per workgroup (one per wave group)
     static constexpr int CIN = CIN_, COUT = COUT_, KH = KH_, KW = KW_, H = H_;
     static constexpr int DILMAX = DILMAX_;   // > 0: frequency-domain use, taps `dil` apart (see ConvCfg)
     static constexpr int MT = MT_, NS = NS_, WMW = WMW_, WQ = WQ_, R = R_;
-    static constexpr int NW = WMW * WQ, NT = NW * 64;
+    static constexpr int NW = WMW * WQ * WCI, NT = NW * 64;
     static constexpr int COB = WMW * MT * 32;
+    static constexpr int CIB = 32 * WCI;
     static constexpr int G = WQ * NS, Q = KH * KW, NQG = (Q + G - 1) / G;
     static constexpr int CW = 64;                            // pixels per K-tile: one image row segment
     static constexpr int PH = KH / 2, PW = KW / 2;
@@ -337,11 +340,11 @@ struct WgCfg {
     static constexpr int PRW = RSPAN, PCW = CW + (KW - 1) * (DILMAX ? DILMAX : 1);
     static constexpr int PS = (PRW * PCW) | 1;               // odd plane stride: lanes (= channels) hit distinct banks
     static constexpr int ZBUF = COB * CW;                    // dZ tile [COB][64], 16-byte chunks XOR-swizzled by co&15
-    static constexpr int XBUF = ((32 * PS + 63) / 64) * 64;
+    static constexpr int XBUF = ((CIB * PS + 63) / 64) * 64;
     static constexpr int NXI = (XBUF / 64 + NW - 1) / NW;    // X-patch DMA instructions per wave
     static constexpr int LDS_BYTES = 2 * (ZBUF + XBUF) * 4;
     static_assert(R == 1, "one image row per K-tile");
-    static_assert(CIN % 32 == 0 && COUT % COB == 0, "tiling");
+    static_assert(CIN % CIB == 0 && COUT % COB == 0, "tiling");
     static_assert(COB % 4 == 0 && MT * NS * 16 <= 160, "accumulator budget");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
@@ -388,7 +391,7 @@ __device__ __forceinline__ void wg_load_tile(const WgArgs& A, int br, int cob, i
     }
     const int hbase = h0 + r0 - C::PH, wbase = w0 - (C::DILMAX ? (C::KW / 2) * A.dil : C::PW);
     const bool interior = hbase >= 0 && hbase + C::PRW <= C::H && wbase >= 0 && wbase + pcw <= T;
-    const float* xbase = A.x + ((size_t)n * C::CIN + (size_t)cit * 32) * C::H * T + (ptrdiff_t)hbase * T + wbase;
+    const float* xbase = A.x + ((size_t)n * C::CIN + (size_t)cit * C::CIB) * C::H * T + (ptrdiff_t)hbase * T + wbase;
 #pragma unroll
     for (int i = 0; i < C::NXI; ++i) {
         const int q = wid + i * C::NW;
@@ -413,11 +416,11 @@ __global__ void __launch_bounds__(C::NT) wgrad_core(WgArgs A) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane_j = lane & 31, lane_h = lane >> 5;
-    const int wq = wid % C::WQ, wmw = wid / C::WQ;
+    const int wq = wid % C::WQ, wci = (wid / C::WQ) % C::WCI, wmw = wid / (C::WQ * C::WCI);
 
     int bid = blockIdx.x;
     const int qg = bid % C::NQG; bid /= C::NQG;
-    const int cit = bid % (C::CIN / 32); bid /= (C::CIN / 32);
+    const int cit = bid % (C::CIN / C::CIB); bid /= (C::CIN / C::CIB);
     const int cob = bid % (C::COUT / C::COB); bid /= (C::COUT / C::COB);
     const int ks = bid % A.KS;
     const int br = bid / A.KS;
@@ -440,7 +443,7 @@ __global__ void __launch_bounds__(C::NT) wgrad_core(WgArgs A) {
     // columns that are read get staged (the LDS buffer is sized for DILMAX)
     const int pcw = C::DILMAX ? C::CW + (C::KW - 1) * A.dil : C::PCW;
     const int ps = C::DILMAX ? ((C::PRW * pcw) | 1) : C::PS;
-    const int nxq = C::DILMAX ? (32 * ps + 63) / 64 : C::XBUF / 64;
+    const int nxq = C::DILMAX ? (C::CIB * ps + 63) / 64 : C::XBUF / 64;
     // X-patch DMA source offsets of this wave (tile independent)
     int xrel[C::NXI], xrc[C::NXI];
 #pragma unroll
@@ -450,7 +453,7 @@ __global__ void __launch_bounds__(C::NT) wgrad_core(WgArgs A) {
         const int rem = L - ci * ps;
         const int row = rem / pcw;
         const int col = rem - row * pcw;
-        const bool ok = ci < 32 && row < C::PRW;
+        const bool ok = ci < C::CIB && row < C::PRW;
         xrel[i] = ok ? (ci * C::H + row) * A.T + col : -1;
         xrc[i] = (row << 16) | col;
     }
@@ -465,7 +468,7 @@ __global__ void __launch_bounds__(C::NT) wgrad_core(WgArgs A) {
         int q = q0 + wq * C::NS + s;
         if (q >= C::Q) q = C::Q - 1;   // padded shift: computed, never stored
         const int rr = q / C::KW, ss = q - rr * C::KW;
-        xoff[s] = lane_j * ps + (rr - r0) * pcw + (C::DILMAX ? ss * A.dil : ss) + 4 * lane_h;
+        xoff[s] = (wci * 32 + lane_j) * ps + (rr - r0) * pcw + (C::DILMAX ? ss * A.dil : ss) + 4 * lane_h;
     }
 
     if (t_begin < t_end) wg_load_tile<C>(A, br, cob, cit, r0, t_begin, zbuf(0), xbuf(0), wid, lane, xrel, xrc, pcw, nxq);
@@ -508,7 +511,7 @@ __global__ void __launch_bounds__(C::NT) wgrad_core(WgArgs A) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int co = cob * C::COB + (wmw * C::MT + m) * 32 + acc_row(k, lane_h);
-                const int ci = cit * 32 + lane_j;
+                const int ci = (cit * C::WCI + wci) * 32 + lane_j;
                 sl[((size_t)q * C::COUT + co) * C::CIN + ci] = acc[m][s][k];
             }
         }
@@ -556,7 +559,7 @@ template <class C>
 static int wg_pick_ks(const ConvArgs& a, int* tiles_total, int* tps) {
     const int ncb = ceil_div(a.T, C::CW);
     const int total = a.B * C::H * ncb;
-    const int base = C::NQG * (C::CIN / 32) * (C::COUT / C::COB) * a.nbr;
+    const int base = C::NQG * (C::CIN / C::CIB) * (C::COUT / C::COB) * a.nbr;
     const int cus = device_cus();
     int best_ks = 1;
     double best_eff = -1.0;

@@ -23,6 +23,7 @@
 namespace zns {
 
 constexpr int FN = 64, FF = 32, FDIL = 16;
+constexpr int FDILW = 12;   // backward-weights tiles keep two input-channel tiles in LDS: window count per row <= 12
 
 __device__ __forceinline__ void twiddle_init(float2* tw) {
     // tw[k] = (cos, sin)(2 pi k / 64), filled by the first 64 threads
@@ -317,11 +318,11 @@ using FD4 = FF4;
 using FD5 = ConvCfg<512, 256, 1, 3, 1, 4, 1, 1, 2, 1, 3, 16, 1, 1, FDIL>;
 using FD6 = FF6;
 //                 CIN' COUT' KH KW(taps) H  MT NS WMW WQ R DILMAX
-using FW2 = WgCfg<128, 128, 1, 7, 1, 2, 4, 2, 2, 1, FDIL>;
-using FW3 = WgCfg<128, 256, 1, 5, 1, 2, 3, 2, 2, 1, FDIL>;
-using FW4 = WgCfg<256, 256, 1, 9, 1, 2, 3, 2, 3, 1, FDIL>;
-using FW5 = WgCfg<256, 512, 1, 3, 1, 2, 3, 4, 1, 1, FDIL>;
-using FW6 = WgCfg<512, 512, 1, 5, 1, 2, 3, 2, 2, 1, FDIL>;
+using FW2 = WgCfg<128, 128, 1, 7, 1, 2, 4, 2, 2, 1, FDILW, 2>;
+using FW3 = WgCfg<128, 256, 1, 5, 1, 2, 3, 2, 2, 1, FDILW, 2>;
+using FW4 = WgCfg<256, 256, 1, 9, 1, 2, 3, 2, 3, 1, FDILW, 2>;
+using FW5 = WgCfg<256, 512, 1, 3, 1, 2, 3, 2, 1, 1, FDILW, 4>;
+using FW6 = WgCfg<512, 512, 1, 5, 1, 2, 3, 2, 2, 1, FDILW, 2>;
 
 struct FftGeom {
     int V, NB, P, nb;
@@ -351,6 +352,8 @@ bool fft_supported(const ConvArgs& a) {
     const FftGeom g = geom(a);
     return g.NB <= FDIL && a.T >= 32;
 }
+
+bool fft_wgrad_supported(const ConvArgs& a) { return fft_supported(a) && geom(a).NB <= FDILW; }
 
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -556,7 +559,7 @@ static int fft_wgrad_t(const ConvArgs& a, const float* dz, const float* x, MPtr2
     A.F = FF;
     A.dil = g.NB;
     A.KS = fwg_pick_ks<W>(a, g, &A.tiles_total, &A.tiles_per_split);
-    const long long blocks = (long long)W::NQG * (W::CIN / 32) * (W::COUT / W::COB) * A.KS * a.nbr * FF;
+    const long long blocks = (long long)W::NQG * (W::CIN / W::CIB) * (W::COUT / W::COB) * A.KS * a.nbr * FF;
     const bool probe = probe_match(2, a.cin, a.cout, a.kh);
     const int slot = probe ? g_probe.count % g_probe.n : 0;
     if (probe) ZNS_HIP(hipEventRecord(g_probe.start[slot], st));

@@ -204,7 +204,7 @@ static int launch_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr
     }
     int rc = set_lds_wg<C>(wgrad_core<C>);
     if (rc) return rc;
-    const long long blocks = (long long)C::NQG * (C::CIN / 32) * (C::COUT / C::COB) * A.KS * a.nbr;
+    const long long blocks = (long long)C::NQG * (C::CIN / C::CIB) * (C::COUT / C::COB) * A.KS * a.nbr;
     const bool probe = probe_match(2, a.cin, a.cout, a.kh);
     const int slot = probe ? g_probe.count % g_probe.n : 0;
     if (probe) ZNS_HIP(hipEventRecord(g_probe.start[slot], st));

@@ -39,6 +39,7 @@ int mfma_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, int
 
 // zns_conv_fft.hip -- frequency-domain (overlap-save) form of cv2..cv6, same results, ~6x fewer MFMA FLOPs
 bool fft_supported(const ConvArgs& a);
+bool fft_wgrad_supported(const ConvArgs& a);
 size_t fft_workspace_bytes(const ConvArgs& a);
 int fft_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, uint8_t* argmax, float drop_p,
             uint32_t seed, int layer, void* ws, size_t ws_bytes, hipStream_t st);
