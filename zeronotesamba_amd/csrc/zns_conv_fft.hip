@@ -39,21 +39,32 @@ __device__ __forceinline__ void twiddle_init(float2* tw) {
 // samples (64 for the overlapped correlation windows, V for the zero-padded blocks of backward-weights' dZ).
 __global__ void __launch_bounds__(256) spec_fwd_kernel(const float* __restrict__ x, float* __restrict__ S, int C,
                                                        int H, int T, int V, int NB, int off, int valid, int chunks) {
+    // Windows are staged through LDS so that global reads are coalesced: one wave-instruction fetches ONE window
+    // (64 consecutive samples); all 64 fetches of a wave are issued before the first LDS write.  Each lane then
+    // reads back its own window (row stride 65 floats: conflict free) and transforms it in registers.
+    __shared__ float win[256 * (FN + 1)];
     const int P = H * NB;
     const int chunk = blockIdx.x % chunks;
     const int plane = blockIdx.x / chunks;          // n * C + c
     const int c = plane % C, n = plane / C;
-    const int p = chunk * 256 + threadIdx.x;
-    if (p >= P) return;
-    const int h = p / NB, b = p - h * NB;
-    const float* row = x + ((size_t)plane * H + h) * T;
-    const int c0 = b * V - off;
+    const int lane = threadIdx.x & 63;
+    const int wbase = (threadIdx.x >> 6) * 64;
+    const float* xp = x + (size_t)plane * H * T;
     float xw[FN];
 #pragma unroll
-    for (int m = 0; m < FN; ++m) {
-        const int col = c0 + m;
-        xw[m] = (m < valid && col >= 0 && col < T) ? row[col] : 0.f;
+    for (int i = 0; i < FN; ++i) {
+        const int pw = chunk * 256 + wbase + i;       // wave-uniform window index
+        const int hh = pw / NB, bb = pw - hh * NB;
+        const int col = bb * V - off + lane;
+        xw[i] = (pw < P && lane < valid && col >= 0 && col < T) ? xp[(size_t)hh * T + col] : 0.f;
     }
+#pragma unroll
+    for (int i = 0; i < FN; ++i) win[(wbase + i) * (FN + 1) + lane] = xw[i];
+    __syncthreads();
+    const int p = chunk * 256 + threadIdx.x;
+    if (p >= P) return;
+#pragma unroll
+    for (int m = 0; m < FN; ++m) xw[m] = win[threadIdx.x * (FN + 1) + m];
     float* out = S + (((size_t)n * FF) * 2 * C + 2 * c) * P + p;
     const size_t fstride = (size_t)2 * C * P;
     float sr[FF], si[FF];
