@@ -14,16 +14,29 @@
 //   backward-data  dx = IDFT( G' . DFT(dz windows) ),  G'[f] = sum_s W[kw-1-s]   e^{+i th f s}, roles of ci/co swapped
 //   backward-wts   dW[s] = IDFT_s( sum_windows conj(DFT(dz V-block, zero padded)) . DFT(x window) )
 //
-// Spectra live in the workspace as S[sample][f = 0..31][2C][P], P = H*NB; slot f = 0 packs the two real bins
-// (DC in "re", Nyquist in "im").  The DFT/IDFT passes are direct 64-point sums on the vector ALU (HBM-bound,
-// <5 % of the step); fusing them into the GEMM epilogues is the next step.
+// Complex products use the 3-multiplication (Karatsuba) form, so each frequency is THREE independent real GEMMs
+//   Q1 = Gr Xr,  Q2 = Gi Xi,  Q3 = (Gr+Gi)(Xr+Xi);   Yr = Q1 - Q2,  Yi = Q3 - Q1 - Q2
+// (backward-weights: R1 = dzr (x) xr, R2 = dzi (x) xi, R3 = (dzr-dzi) (x) (xr+xi); re = R1+R2, im = R3-R1+R2),
+// i.e. 3*32 real MACs per window position instead of V*kw: 6.8x (cv2) .. 9.4x (cv6) fewer than the direct form.
+// Spectra live in the workspace as S[sample][slot = 3 f + t][C][P], P = H*NB, planes t = (re, im, re +/- im);
+// frequency slot 0 carries the two real bins (DC in t = 0, Nyquist in t = 1, t = 2 unused).
 #include "zns_conv_core.h"
 #include "zns_fft64.h"
 
 namespace zns {
 
 constexpr int FN = 64, FF = 32, FDIL = 16;
+constexpr int FS = 3 * FF;   // weight/spectrum slots per sample: (frequency f, Karatsuba part t) -> 3 f + t
 constexpr int FDILW = 12;   // backward-weights tiles keep two input-channel tiles in LDS: window count per row <= 12
+
+// Spectrum planes are addressed as  (per-lane byte offset, wave-uniform plane offset)  through a buffer
+// descriptor: the 96 plane accesses of a window then share ONE address VGPR (the plane offset goes in an SGPR).
+__device__ __forceinline__ float spec_load(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+}
+__device__ __forceinline__ void spec_store(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 0);
+}
 
 __device__ __forceinline__ void twiddle_init(float2* tw) {
     // tw[k] = (cos, sin)(2 pi k / 64), filled by the first 64 threads
@@ -38,7 +51,8 @@ __device__ __forceinline__ void twiddle_init(float2* tw) {
 // x [nb, C, H, T] -> S [nb][FF][2C][P].  Window of block b starts at column b*V - off and has `valid` live
 // samples (64 for the overlapped correlation windows, V for the zero-padded blocks of backward-weights' dZ).
 __global__ void __launch_bounds__(256) spec_fwd_kernel(const float* __restrict__ x, float* __restrict__ S, int C,
-                                                       int H, int T, int V, int NB, int off, int valid, int chunks) {
+                                                       int H, int T, int V, int NB, int off, int valid, int chunks,
+                                                       float third_sign) {
     // Windows are staged through LDS so that global reads are coalesced: one wave-instruction fetches ONE window
     // (64 consecutive samples); all 64 fetches of a wave are issued before the first LDS write.  Each lane then
     // reads back its own window (row stride 65 floats: conflict free) and transforms it in registers.
@@ -65,14 +79,15 @@ __global__ void __launch_bounds__(256) spec_fwd_kernel(const float* __restrict__
     if (p >= P) return;
 #pragma unroll
     for (int m = 0; m < FN; ++m) xw[m] = win[threadIdx.x * (FN + 1) + m];
-    float* out = S + (((size_t)n * FF) * 2 * C + 2 * c) * P + p;
-    const size_t fstride = (size_t)2 * C * P;
+    float* out = S + (((size_t)n * FS) * C + c) * P + p;
+    const size_t tstride = (size_t)C * P;       // between the three planes of one frequency
     float sr[FF], si[FF];
     rfft64(xw, sr, si);
 #pragma unroll
     for (int f = 0; f < FF; ++f) {
-        out[f * fstride] = sr[f];
-        out[f * fstride + P] = si[f];
+        out[(3 * f) * tstride] = sr[f];
+        out[(3 * f + 1) * tstride] = si[f];
+        out[(3 * f + 2) * tstride] = f ? sr[f] + third_sign * si[f] : 0.f;
     }
 }
 
@@ -109,36 +124,43 @@ __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__
     const int pq = chunk * 256 + threadIdx.x;
     const bool active = pq < Pq;
     const int P = H * NB;
-    const size_t fstride = (size_t)2 * C * P;
+    const unsigned tstride = (unsigned)C * P * 4u;       // bytes between consecutive slots
+    float* sbase = const_cast<float*>(S) + (((size_t)n * FS) * C + c) * P;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(sbase, 0, (int)(tstride * (FS - 1) + P * 4u), 0x00020000);
     if (active) {
         const int hq = pq / NB, b = pq - hq * NB;
-        float best[IVMAX];
-        int am[(IVMAX + 3) / 4];
-#pragma unroll
-        for (int i = 0; i < (IVMAX + 3) / 4; ++i) am[i] = 0;
+        float* mine = stage + threadIdx.x * IVS;          // running maximum lives in LDS, not in 52 more registers
+#pragma unroll 1
         for (int a = 0; a < pool; ++a) {
             const int h = hq * pool + a;
-            const float* in = S + (((size_t)n * FF) * 2 * C + 2 * c) * P + (size_t)h * NB + b;
+            const unsigned voff = (unsigned)(h * NB + b) * 4u;
             float yr[FF], yi[FF];
+            yr[0] = spec_load(rs, voff, 0);                  // DC
+            yi[0] = spec_load(rs, voff, tstride);            // Nyquist
 #pragma unroll
-            for (int f = 0; f < FF; ++f) {
-                yr[f] = in[f * fstride];
-                yi[f] = in[f * fstride + P];
+            for (int f = 1; f < FF; ++f) {
+                const float q1 = spec_load(rs, voff, (3 * f) * tstride), q2 = spec_load(rs, voff, (3 * f + 1) * tstride),
+                            q3 = spec_load(rs, voff, (3 * f + 2) * tstride);
+                yr[f] = q1 - q2;
+                yi[f] = q3 - q1 - q2;
             }
             float xo[FN];
             irfft64(yr, yi, xo);
+            if (a == 0) {
 #pragma unroll
-            for (int v = 0; v < IVMAX; ++v) {
-                if (a == 0 || xo[v] > best[v]) {       // first maximum wins, as ATen's max_pool2d
-                    best[v] = xo[v];
-                    if (MODE == 1 && a) am[v >> 2] = (am[v >> 2] & ~(0xff << ((v & 3) * 8))) | (a << ((v & 3) * 8));
+                for (int v = 0; v < IVMAX; ++v) {
+                    mine[v] = xo[v];
+                    if (MODE == 1) stage_am[threadIdx.x * IVMAX + v] = 0;
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < IVMAX; ++v) {
+                    if (xo[v] > mine[v]) {             // first maximum wins, as ATen's max_pool2d
+                        mine[v] = xo[v];
+                        stage_am[threadIdx.x * IVMAX + v] = (uint8_t)a;
+                    }
                 }
             }
-        }
-#pragma unroll
-        for (int v = 0; v < IVMAX; ++v) {
-            stage[threadIdx.x * IVS + v] = best[v];
-            if (MODE == 1) stage_am[threadIdx.x * IVMAX + v] = (uint8_t)((am[v >> 2] >> ((v & 3) * 8)) & 0xff);
         }
     }
     __syncthreads();
@@ -182,34 +204,32 @@ __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__
     }
 }
 
-// Frequency weights in conv_core's slab order for the real-embedded operator (CIN_c = 2*cin_c, COUT_c = 2*cout_c,
-// 1 x kh taps):  [branch*FF + f][cob][cc][cp][tap][wm][lane_h][i][m].
-// One thread owns one complex entry G(co, ci, tap) -- i.e. the 2x2 real block [[gr, -gi], [gi, gr]] that sits at
-// (lane_h, i) in {0,1} x {2*ih, 2*ih+1} of the slab -- reads its kw time taps once and loops over the 32 frequency
-// slots, so the weights are read once and every slab is written with coalesced stores.
+// Frequency weights in conv_core's slab order: three REAL [cout_c x cin_c*kh] operators per frequency
+//   slot 3f+0: Gr   slot 3f+1: Gi   slot 3f+2: Gr + Gi      (f = 0: G(0), G(32), unused)
+// laid out [branch*FS + slot][cob][cc][cp][tap][wm][lane_h][i][m].  One thread owns one (co, ci, tap): it reads the
+// kw time taps once and loops over the 32 frequencies, so every slab is written with coalesced stores.
 __global__ void __launch_bounds__(256) pack_freq_weights_kernel(Ptr2 w, float* __restrict__ dst, int cin_c, int cout_c,
                                                                 int kh, int kw, int cob_sz, int ck, int mt, int wm_n,
                                                                 int transposed, long long per_wf, int nbr) {
     __shared__ float2 tw[FN];
     twiddle_init(tw);
     __syncthreads();
-    const long long quads = per_wf / 4;
     const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= quads * nbr) return;
-    const int br = (int)(o / quads);
-    long long q = o % quads;
+    if (o >= per_wf * nbr) return;
+    const int br = (int)(o / per_wf);
+    long long q = o % per_wf;                       // offset inside one slab = the slab layout itself
+    const long long off = q;
     const int m = (int)(q % mt); q /= mt;
-    const int ih = (int)(q % 16); q /= 16;
+    const int i = (int)(q % 32); q /= 32;
+    const int h = (int)(q % 2); q /= 2;
     const int wm = (int)(q % wm_n); q /= wm_n;
     const int tap = (int)(q % kh); q /= kh;
     const int cp = (int)(q % (ck / 2)); q /= (ck / 2);
-    const int ncc = 2 * cin_c / ck;
+    const int ncc = cin_c / ck;
     const int cc = (int)(q % ncc); q /= ncc;
     const int cob = (int)q;
-    const int co = (cob * cob_sz + (wm * mt + m) * 32 + 2 * ih) >> 1;   // complex output channel
-    const int ci = ((cc * ck) >> 1) + cp;                                // complex input channel
-    // slab offset of the (lane_h = 0, i = 2*ih) entry; i + 1 is mt floats further, lane_h = 1 is 32*mt further
-    const long long off = ((((((long long)cob * ncc + cc) * (ck / 2) + cp) * kh + tap) * wm_n + wm) * 64 + 2 * ih) * mt + m;
+    const int co = cob * cob_sz + (wm * mt + m) * 32 + i;
+    const int ci = cc * ck + 2 * cp + h;
     float wt[25];
     if (!transposed) {
         const float* wr = w.p[br] + (((size_t)co * cin_c + ci) * kh + tap) * kw;                     // W[co][ci][tap][s]
@@ -221,7 +241,7 @@ __global__ void __launch_bounds__(256) pack_freq_weights_kernel(Ptr2 w, float* _
 #pragma unroll
         for (int s = 0; s < 25; ++s) wt[s] = s < kw ? wr[kw - 1 - s] : 0.f;
     }
-    float* d = dst + (size_t)br * FF * per_wf + off;
+    float* d = dst + (size_t)br * FS * per_wf + off;
     {
         float g0 = 0.f, g32 = 0.f;
 #pragma unroll
@@ -229,10 +249,9 @@ __global__ void __launch_bounds__(256) pack_freq_weights_kernel(Ptr2 w, float* _
             g0 += wt[s];
             g32 += (s & 1) ? -wt[s] : wt[s];
         }
-        d[0] = g0;                 // (re <- re)
-        d[mt] = 0.f;               // (im <- re)
-        d[32 * mt] = 0.f;          // (re <- im)
-        d[32 * mt + mt] = g32;     // (im <- im): Nyquist
+        d[0] = g0;
+        d[per_wf] = g32;
+        d[2 * per_wf] = 0.f;
     }
     for (int f = 1; f < FF; ++f) {
         float gr = 0.f, gi = 0.f;
@@ -242,15 +261,14 @@ __global__ void __launch_bounds__(256) pack_freq_weights_kernel(Ptr2 w, float* _
             gr = fmaf(wt[s], t.x, gr);
             gi = fmaf(wt[s], t.y, gi);
         }
-        float* df = d + (size_t)f * per_wf;
+        float* df = d + (size_t)(3 * f) * per_wf;
         df[0] = gr;
-        df[mt] = gi;
-        df[32 * mt] = -gi;
-        df[32 * mt + mt] = gr;
+        df[per_wf] = gi;
+        df[2 * per_wf] = gr + gi;
     }
 }
 
-// slab [br*FF + f][ks][tap][2*cout][2*cin] (the four real products of conj(dZ).X) -> dW[co][ci][tap][s]
+// slab [br*FS + 3f+t][ks][tap][cout][cin] (R1 = dzr(x)xr, R2 = dzi(x)xi, R3 = (dzr-dzi)(x)(xr+xi)) -> dW[co][ci][tap][s]
 __global__ void wgrad_spec_reduce_kernel(const float* __restrict__ slab, MPtr2 dw, int KS, int cout, int cin, int kh,
                                          int kw, int accumulate, int nbr) {
     __shared__ float2 tw[FN];
@@ -258,8 +276,7 @@ __global__ void wgrad_spec_reduce_kernel(const float* __restrict__ slab, MPtr2 d
     __syncthreads();
     const long long per = (long long)cout * cin * kh;
     const long long total = per * nbr;
-    const int CO2 = 2 * cout, CI2 = 2 * cin;
-    const size_t per_ks = (size_t)kh * CO2 * CI2;
+    const size_t per_ks = (size_t)kh * cout * cin;
     for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < total;
          o += (long long)gridDim.x * blockDim.x) {
         const int br = (int)(o / per);
@@ -267,16 +284,18 @@ __global__ void wgrad_spec_reduce_kernel(const float* __restrict__ slab, MPtr2 d
         const int ci = (int)(e % cin); e /= cin;
         const int co = (int)(e % cout);
         const int tap = (int)(e / cout);
+        const size_t eoff = ((size_t)tap * cout + co) * cin + ci;
         float cr[FF], cim[FF];
         for (int f = 0; f < FF; ++f) {
-            float g00 = 0.f, g01 = 0.f, g10 = 0.f, g11 = 0.f;
-            const float* sp = slab + ((size_t)(br * FF + f) * KS) * per_ks + ((size_t)tap * CO2 + 2 * co) * CI2 + 2 * ci;
+            float r1 = 0.f, r2 = 0.f, r3 = 0.f;
+            const float* sp = slab + ((size_t)(br * FS + 3 * f) * KS) * per_ks + eoff;
             for (int k = 0; k < KS; ++k) {
-                const float* q = sp + (size_t)k * per_ks;
-                g00 += q[0]; g01 += q[1]; g10 += q[CI2]; g11 += q[CI2 + 1];
+                r1 += sp[(size_t)k * per_ks];
+                r2 += sp[((size_t)KS + k) * per_ks];
+                r3 += sp[((size_t)2 * KS + k) * per_ks];
             }
-            if (f == 0) { cr[0] = g00; cim[0] = g11; }           // DC and Nyquist, both real
-            else { cr[f] = g00 + g11; cim[f] = g01 - g10; }       // conj(dz) * x
+            if (f == 0) { cr[0] = r1; cim[0] = r2; }              // DC and Nyquist, both real
+            else { cr[f] = r1 + r2; cim[f] = r3 - r1 + r2; }       // conj(dz) * x
         }
         float* d = dw.p[br] + (((size_t)co * cin + ci) * kh + tap) * kw;
         for (int s = 0; s < kw; ++s) {
@@ -300,7 +319,7 @@ __global__ void __launch_bounds__(256) spec_dc_sum_kernel(const float* __restric
     const int co = blockIdx.x % C, br = blockIdx.x / C;
     float acc = 0.f;
     for (int b = 0; b < B; ++b) {
-        const float* sp = sz + (((size_t)(br * B + b) * FF) * 2 * C + 2 * co) * P;
+        const float* sp = sz + (((size_t)(br * B + b) * FS) * C + co) * P;
         for (int p = threadIdx.x; p < P; p += 256) acc += sp[p];
     }
 #pragma unroll
@@ -317,23 +336,23 @@ __global__ void __launch_bounds__(256) spec_dc_sum_kernel(const float* __restric
 // =====================================================================================================
 //                                          instances + dispatch
 // =====================================================================================================
-//                  CIN' COUT' KH KW(taps) H  MT RT CT WM WR WC CK POOL EPI DILMAX
-using FF2 = ConvCfg<128, 128, 1, 7, 1, 4, 1, 1, 1, 1, 8, 8, 1, 1, FDIL>;
-using FF3 = ConvCfg<128, 256, 1, 5, 1, 4, 1, 1, 2, 1, 4, 8, 1, 1, FDIL>;
-using FF4 = ConvCfg<256, 256, 1, 9, 1, 4, 1, 1, 2, 1, 6, 4, 1, 1, FDIL>;
-using FF5 = ConvCfg<256, 512, 1, 3, 1, 4, 1, 1, 2, 1, 3, 16, 1, 1, FDIL>;
-using FF6 = ConvCfg<512, 512, 1, 5, 1, 4, 1, 1, 2, 1, 3, 8, 1, 1, FDIL>;
+//                  CIN COUT KH KW(taps) H  MT RT CT WM WR WC CK POOL EPI DILMAX
+using FF2 = ConvCfg<64, 64, 1, 7, 1, 2, 1, 2, 1, 1, 5, 8, 1, 1, FDIL>;
+using FF3 = ConvCfg<64, 128, 1, 5, 1, 4, 1, 1, 1, 1, 11, 8, 1, 1, FDIL>;
+using FF4 = ConvCfg<128, 128, 1, 9, 1, 4, 1, 1, 1, 1, 11, 8, 1, 1, FDIL>;
+using FF5 = ConvCfg<128, 256, 1, 3, 1, 4, 1, 1, 2, 1, 3, 16, 1, 1, FDIL>;
+using FF6 = ConvCfg<256, 256, 1, 5, 1, 4, 1, 1, 2, 1, 3, 8, 1, 1, FDIL>;
 using FD2 = FF2;
-using FD3 = ConvCfg<256, 128, 1, 5, 1, 4, 1, 1, 1, 1, 4, 8, 1, 1, FDIL>;
+using FD3 = ConvCfg<128, 64, 1, 5, 1, 2, 1, 1, 1, 1, 11, 8, 1, 1, FDIL>;
 using FD4 = FF4;
-using FD5 = ConvCfg<512, 256, 1, 3, 1, 4, 1, 1, 2, 1, 3, 16, 1, 1, FDIL>;
+using FD5 = ConvCfg<256, 128, 1, 3, 1, 2, 1, 1, 2, 1, 3, 16, 1, 1, FDIL>;
 using FD6 = FF6;
-//                 CIN' COUT' KH KW(taps) H  MT NS WMW WQ R DILMAX
-using FW2 = WgCfg<128, 128, 1, 7, 1, 2, 4, 2, 2, 1, FDILW, 2>;
-using FW3 = WgCfg<128, 256, 1, 5, 1, 2, 3, 2, 2, 1, FDILW, 2>;
-using FW4 = WgCfg<256, 256, 1, 9, 1, 2, 3, 2, 3, 1, FDILW, 2>;
-using FW5 = WgCfg<256, 512, 1, 3, 1, 2, 3, 2, 1, 1, FDILW, 4>;
-using FW6 = WgCfg<512, 512, 1, 5, 1, 2, 3, 2, 2, 1, FDILW, 2>;
+//                 CIN COUT KH KW(taps) H  MT NS WMW WQ R DILMAX WCI
+using FW2 = WgCfg<64, 64, 1, 7, 1, 1, 4, 2, 2, 1, FDILW, 2>;
+using FW3 = WgCfg<64, 128, 1, 5, 1, 2, 3, 2, 2, 1, FDILW, 2>;
+using FW4 = WgCfg<128, 128, 1, 9, 1, 2, 3, 2, 3, 1, FDILW, 2>;
+using FW5 = WgCfg<128, 256, 1, 3, 1, 2, 3, 2, 1, 1, FDILW, 4>;
+using FW6 = WgCfg<256, 256, 1, 5, 1, 2, 3, 2, 2, 1, FDILW, 2>;
 
 struct FftGeom {
     int V, NB, P, nb;
@@ -376,7 +395,7 @@ template <class W>
 static int fwg_pick_ks(const ConvArgs& a, const FftGeom& g, int* tiles_total, int* tps) {
     ConvArgs t = a;
     t.T = g.P;           // K tiles run over the flattened axis
-    t.nbr = a.nbr * FF;  // one accumulation per (branch, frequency)
+    t.nbr = a.nbr * FS;  // one accumulation per (branch, frequency, Karatsuba part)
     return wg_pick_ks<W>(t, tiles_total, tps);
 }
 
@@ -384,19 +403,19 @@ template <class W>
 static size_t fwg_slab_floats(const ConvArgs& a, const FftGeom& g) {
     int tt, tps;
     const int ks = fwg_pick_ks<W>(a, g, &tt, &tps);
-    return (size_t)a.nbr * FF * ks * W::Q * W::COUT * W::CIN;
+    return (size_t)a.nbr * FS * ks * W::Q * W::COUT * W::CIN;
 }
 
 static FftWs fft_ws(const ConvArgs& a) {
     const FftGeom g = geom(a);
     FftWs w{};
     const size_t cmax = (size_t)(a.cin > a.cout ? a.cin : a.cout);
-    const size_t spec = (size_t)g.nb * FF * 2 * cmax * g.P * sizeof(float);
+    const size_t spec = (size_t)g.nb * FS * cmax * g.P * sizeof(float);
     w.s_in = 0;
     w.s_out = align_up(spec);
     w.z = w.s_out + align_up(spec);
     w.wf = w.z + align_up((size_t)g.nb * cmax * a.H * a.T * sizeof(float));
-    const size_t wfb = (size_t)a.nbr * FF * 4 * a.cout * a.cin * a.kh * sizeof(float);
+    const size_t wfb = (size_t)a.nbr * FS * a.cout * a.cin * a.kh * sizeof(float);
     size_t slab = 0;
     switch (fft_layer_of(a)) {
         case 2: slab = fwg_slab_floats<FW2>(a, g); break;
@@ -414,10 +433,10 @@ static FftWs fft_ws(const ConvArgs& a) {
 size_t fft_workspace_bytes(const ConvArgs& a) { return fft_supported(a) ? fft_ws(a).total : 0; }
 
 static int run_spec_fwd(const float* x, float* S, int nb, int C, int H, int T, const FftGeom& g, int off, int valid,
-                        hipStream_t st) {
+                        float third_sign, hipStream_t st) {
     const int chunks = ceil_div(g.P, 256);
     hipLaunchKernelGGL(spec_fwd_kernel, dim3((unsigned)((size_t)nb * C * chunks)), dim3(256), 0, st, x, S, C, H, T, g.V,
-                       g.NB, off, valid, chunks);
+                       g.NB, off, valid, chunks, third_sign);
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
 }
@@ -456,10 +475,9 @@ static int set_lds_fw(void (*kern)(WgArgs)) {
 template <class C>
 static int run_fconv(const ConvArgs& a, const FftGeom& g, Ptr2 w, int transposed, const float* s_in, float* s_out,
                      float* wf, int probe_kind, hipStream_t st) {
-    // pack: the core's CIN/COUT are the real-embedded channel counts
-    const int cin_c = C::CIN / 2, cout_c = C::COUT / 2;
+    const int cin_c = C::CIN, cout_c = C::COUT;
     const long long per_wf = (long long)C::COUT * C::CIN * C::KW;
-    const long long total = per_wf / 4 * a.nbr;
+    const long long total = per_wf * a.nbr;
     const int blocks = (int)((total + 255) / 256);
     hipLaunchKernelGGL(pack_freq_weights_kernel, dim3(blocks), dim3(256), 0, st, w, wf, cin_c, cout_c, C::KW, a.kw,
                        C::COB, C::CK, C::MT, C::WM, transposed, per_wf, a.nbr);
@@ -475,8 +493,8 @@ static int run_fconv(const ConvArgs& a, const FftGeom& g, Ptr2 w, int transposed
     A.prev_pool = 1;
     A.B = a.B;
     A.T = g.P;
-    A.N = g.nb * FF;
-    A.F = FF;
+    A.N = g.nb * FS;
+    A.F = FS;
     A.dil = g.NB;
     A.ncb = ceil_div(g.P, C::WB);
     const long long blocks2 = (long long)A.N * A.ncb * (C::COUT / C::COB);
@@ -500,7 +518,7 @@ static int fft_fwd_t(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float
     float* s_out = (float*)(base + L.s_out);
     float* z = (float*)(base + L.z);
     float* wf = (float*)(base + L.wf);
-    int rc = run_spec_fwd(x, s_in, g.nb, a.cin, a.H, a.T, g, a.kw / 2, FN, st);
+    int rc = run_spec_fwd(x, s_in, g.nb, a.cin, a.H, a.T, g, a.kw / 2, FN, 1.f, st);
     if (rc) return rc;
     rc = run_fconv<C>(a, g, w, 0, s_in, s_out, wf, 0, st);
     if (rc) return rc;
@@ -528,7 +546,7 @@ static int fft_dgrad_t(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, co
     float* s_out = (float*)(base + L.s_out);
     float* z = (float*)(base + L.z);
     float* wf = (float*)(base + L.wf);
-    int rc = run_spec_fwd(dz, s_in, g.nb, a.cout, a.H, a.T, g, a.kw / 2, FN, st);
+    int rc = run_spec_fwd(dz, s_in, g.nb, a.cout, a.H, a.T, g, a.kw / 2, FN, 1.f, st);
     if (rc) return rc;
     rc = run_fconv<C>(a, g, w, 1, s_in, s_out, wf, 1, st);
     if (rc) return rc;
@@ -551,9 +569,9 @@ static int fft_wgrad_t(const ConvArgs& a, const float* dz, const float* x, MPtr2
     float* sx = (float*)(base + L.s_in);
     float* sz = (float*)(base + L.s_out);
     float* slab = (float*)(base + L.slab);
-    int rc = run_spec_fwd(x, sx, g.nb, a.cin, a.H, a.T, g, a.kw / 2, FN, st);   // correlation windows of the input
+    int rc = run_spec_fwd(x, sx, g.nb, a.cin, a.H, a.T, g, a.kw / 2, FN, 1.f, st);   // windows of the input: (xr, xi, xr+xi)
     if (rc) return rc;
-    rc = run_spec_fwd(dz, sz, g.nb, a.cout, a.H, a.T, g, 0, g.V, st);           // zero-padded V-blocks of dZ
+    rc = run_spec_fwd(dz, sz, g.nb, a.cout, a.H, a.T, g, 0, g.V, -1.f, st);     // zero-padded V-blocks of dZ: (r, i, r-i)
     if (rc) return rc;
     hipLaunchKernelGGL(spec_dc_sum_kernel, dim3(a.nbr * a.cout), dim3(256), 0, st, (const float*)sz, db, a.B, a.cout,
                        g.P, accumulate);
@@ -567,10 +585,10 @@ static int fft_wgrad_t(const ConvArgs& a, const float* dz, const float* x, MPtr2
     A.B = a.B;
     A.T = g.P;
     A.ncb = ceil_div(g.P, W::CW);
-    A.F = FF;
+    A.F = FS;
     A.dil = g.NB;
     A.KS = fwg_pick_ks<W>(a, g, &A.tiles_total, &A.tiles_per_split);
-    const long long blocks = (long long)W::NQG * (W::CIN / W::CIB) * (W::COUT / W::COB) * A.KS * a.nbr * FF;
+    const long long blocks = (long long)W::NQG * (W::CIN / W::CIB) * (W::COUT / W::COB) * A.KS * a.nbr * FS;
     const bool probe = probe_match(2, a.cin, a.cout, a.kh);
     const int slot = probe ? g_probe.count % g_probe.n : 0;
     if (probe) ZNS_HIP(hipEventRecord(g_probe.start[slot], st));
