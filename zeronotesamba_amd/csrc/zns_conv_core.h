@@ -13,7 +13,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-static __device__ const float g_zero_page[16] = {0};
+static __device__ const float g_zero_page[16] __attribute__((aligned(16))) = {0};
 
 __device__ __forceinline__ void glds4(const float* src, float* lds_dst) {
     __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)lds_dst, 4, 0, 0);
@@ -41,9 +41,11 @@ struct ConvCfg {
     static constexpr int NW = WM * WR * WC, NT = NW * 64;
     static constexpr int COB = WM * MT * 32, RB = WR * RT, WB = WC * CT * 32;
     static constexpr int PH = KH / 2, PW = KW / 2;
-    static constexpr int PR = RB + KH - 1, PCW = WB + (KW - 1) * (DILMAX ? DILMAX : 1);
-    static constexpr int PS = (PR * PCW) | 1;                 // odd plane stride
-    static constexpr int PATCH = ((CK * PS + 63) / 64) * 64;  // floats per patch buffer
+    // Patch rows start at a 16-byte aligned image column (w0 - pw rounded down to a multiple of 4) and are a
+    // multiple of 4 floats long, so the patch can be staged with 16-byte LDS-DMA whenever T % 4 == 0.
+    static constexpr int PR = RB + KH - 1, PCW = (WB + (KW - 1) * (DILMAX ? DILMAX : 1) + 3 + 3) / 4 * 4;
+    static constexpr int PS = (PR * PCW + 3) / 4 * 4;         // plane stride, 16-byte aligned
+    static constexpr int PATCH = ((CK * PS + 255) / 256) * 256;  // floats per patch buffer (whole 1-KiB DMA pieces)
     static constexpr int SLAB = CK * KW * COB;                // floats per weight stage
     static constexpr int NCC = CIN / CK, NST = NCC * KH;
     static constexpr int LDS_BYTES = (2 * SLAB + 2 * PATCH) * 4;
@@ -85,22 +87,26 @@ struct CoreArgs {
 // padding -> zero page); staging a ci-chunk is then one add + select per instruction.
 template <class C>
 struct PatchPlan {
-    static constexpr int NPI = (C::PATCH / 64 + C::NW - 1) / C::NW;
+    static constexpr int NPI = (C::PATCH / 64 + C::NW - 1) / C::NW;   // 4-byte pieces per wave (16-byte mode uses a quarter)
     int rel[NPI];
+    bool wide;                                                         // 16-byte DMA pieces (wave-uniform)
 };
 
+// pw_al = image columns between the patch origin and the tile origin (multiple of 4, >= the padding pw)
 template <class C>
-__device__ __forceinline__ void patch_offsets(PatchPlan<C>& pl, int h0, int w0, int T, int wid, int lane, int pw,
-                                              int live_cols) {
+__device__ __forceinline__ void patch_offsets(PatchPlan<C>& pl, const float* xn, int h0, int w0, int T, int wid, int lane,
+                                              int pw_al, int live_cols) {
+    pl.wide = ((T & 3) == 0) && ((reinterpret_cast<uintptr_t>(xn) & 15) == 0);
 #pragma unroll
     for (int i = 0; i < PatchPlan<C>::NPI; ++i) {
-        const int L = (wid + i * C::NW) * 64 + lane;
+        const int L = ((wid + i * C::NW) * 64 + lane) * (pl.wide ? 4 : 1);
         const int ci = L / C::PS;
         const int rem = L - ci * C::PS;
         const int row = rem / C::PCW;
         const int col = rem - row * C::PCW;
-        const int hh = h0 - C::PH + row, ww = w0 - pw + col;
-        const bool ok = (ci < C::CK) && (row < C::PR) && (col < live_cols) && hh >= 0 && hh < C::H && ww >= 0 && ww < T;
+        const int hh = h0 - C::PH + row, ww = w0 - pw_al + col;
+        // T % 4 == 0 and a 4-aligned origin: a 16-byte piece is entirely inside or entirely outside the image
+        const bool ok = (L < C::CK * C::PS) && (row < C::PR) && (col < live_cols) && hh >= 0 && hh < C::H && ww >= 0 && ww < T;
         pl.rel[i] = ok ? (ci * C::H + hh) * T + ww : -1;
     }
 }
@@ -109,10 +115,18 @@ template <class C>
 __device__ __forceinline__ void load_patch(const PatchPlan<C>& pl, const float* xn, int cc, int T, float* lds_patch,
                                            int wid) {
     const float* base = xn + (size_t)cc * C::CK * C::H * T;
+    if (pl.wide) {
 #pragma unroll
-    for (int i = 0; i < PatchPlan<C>::NPI; ++i) {
-        const int q = wid + i * C::NW;
-        if (q < C::PATCH / 64) glds4(pl.rel[i] >= 0 ? base + pl.rel[i] : g_zero_page, lds_patch + q * 64);
+        for (int i = 0; i < (PatchPlan<C>::NPI + 3) / 4; ++i) {
+            const int q = wid + i * C::NW;
+            if (q < C::PATCH / 256) glds16(pl.rel[i] >= 0 ? base + pl.rel[i] : g_zero_page, lds_patch + q * 256);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PatchPlan<C>::NPI; ++i) {
+            const int q = wid + i * C::NW;
+            if (q < C::PATCH / 64) glds4(pl.rel[i] >= 0 ? base + pl.rel[i] : g_zero_page, lds_patch + q * 64);
+        }
     }
 }
 
@@ -197,10 +211,12 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
                 for (int k = 0; k < 16; ++k) acc[m][rt][ct][k] = 0.f;
 
     const int abase = wm * (64 * C::MT) + lane * C::MT;
-    const int bbase = lane_h * C::PS + (wr * C::RT) * C::PCW + wc * C::CT * 32 + lane_j;
+    const int pw_al = (pw + 3) & ~3;   // patch origin = tile origin - pw_al (16-byte aligned); reads skip pw_al - pw
+    const int bbase = lane_h * C::PS + (wr * C::RT) * C::PCW + wc * C::CT * 32 + lane_j + (pw_al - pw);
 
     PatchPlan<C> plan;
-    patch_offsets<C>(plan, h0, w0, T, wid, lane, pw, C::DILMAX ? C::WB + (C::KW - 1) * dil : C::PCW);
+    patch_offsets<C>(plan, xn, h0, w0, T, wid, lane, pw_al,
+                     (C::DILMAX ? C::WB + (C::KW - 1) * dil : C::WB + C::KW - 1) + (pw_al - pw));
     load_patch<C>(plan, xn, 0, T, patch(0), wid);
     load_slab<C>(wbase, slab(0), wid, lane);
 
