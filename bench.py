@@ -36,19 +36,19 @@ LAYER_GEOM = {"cv2": (64, 64, 7, 13, 96), "cv3": (64, 128, 5, 15, 32), "cv4": (1
 
 def spectral_flop(layer: str, useful: bool) -> float:
     """FLOP of ONE pass (fwd, dgrad or wgrad) of `layer` in the frequency-domain form, both branches, B=16:
-    32 frequency slots x (2*cout) x (2*cin*kh) real MACs per window position (executed), of which slot 0 only
-    needs its two real products (useful).  Tile padding is not counted."""
+    32 frequencies x 3 real GEMMs (Karatsuba) of cout x (cin*kh) per window position (executed); frequency slot 0
+    (DC + Nyquist, both real) needs only two of its three (useful).  Tile padding is not counted."""
     cin, cout, kh, kw, H = LAYER_GEOM[layer]
     V = 64 - kw + 1
     P = H * (-(-T // V))
-    slots = (31 * 4 + 2) if useful else 32 * 4
+    slots = (31 * 3 + 2) if useful else 32 * 3
     return 2.0 * slots * cout * cin * kh * P * (2 * B)
 
 
 # MFMA FLOP actually executed per step: cv2..cv6 in the frequency domain (3 passes), cv7/cv8 direct (3 passes)
 EXEC_FLOP = 3 * sum(spectral_flop(l, False) for l in LAYER_GEOM) + 3 * 2 * 2 * B * (MACS["cv7"] + MACS["cv8"])
 # dominant kernel (profiles/): the frequency-domain forward GEMM-conv of cv4 (conv_core<256,256,1x9 taps>)
-PROBE = dict(kind=0, cin=128, cout=128, kh=9, name="conv_core<spectral cv4 forward: 256x256 real-embedded, 9 row taps>",
+PROBE = dict(kind=0, cin=128, cout=128, kh=9, name="conv_core<spectral cv4 forward: 96 real 128x1152 GEMM-convs per sample, 9 row taps>",
              flop=spectral_flop("cv4", True))
 
 

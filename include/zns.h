@@ -67,11 +67,15 @@ int zns_probe_count(void);
  * of (seed, layer, branch, linear index of y within its branch); see csrc/zns_common.h.
  */
 size_t zns_conv2d_workspace_bytes(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H);
+/* Bytes of the input spectrum the forward pass can hand to backward-weights (0 when this geometry does not use
+ * the frequency-domain kernels): pass a buffer of that size as `xspec` to BOTH calls to skip recomputing it. */
+size_t zns_conv2d_spectrum_bytes(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H);
 
 int zns_conv2d_fwd_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, int pool,
                        const float* x, const float* const* w, const float* const* bias,
                        float* y, uint8_t* argmax,
                        float drop_p, uint32_t seed, int layer,
+                       float* xspec /* nullable: receives the input spectrum, see zns_conv2d_spectrum_bytes */,
                        void* ws, size_t ws_bytes, void* stream);
 
 /* Backward-data of the same conv (autograd of models.py:37-70):
@@ -93,7 +97,8 @@ int zns_conv2d_dgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int k
  * accumulate != 0 adds into dw/db (gradient accumulation), else overwrites. */
 int zns_conv2d_wgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H,
                          const float* dz, const float* x, float* const* dw, float* const* db,
-                         int accumulate, void* ws, size_t ws_bytes, void* stream);
+                         int accumulate, const float* xspec /* nullable: spectrum saved by the forward call */,
+                         void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ DS_CNN head
  * emb[n, t] = sigmoid(sum_c w[c] * h[n, c, t] + b)   (fc1 + sig + reshape, models.py:99-101) */

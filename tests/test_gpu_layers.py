@@ -70,7 +70,7 @@ def test_conv_layer(li, impl, T):
         bd = [t.to(dev) for t in b]
         ws = _ops.workspace(_ops.conv_workspace_bytes(nbr, B, T), dev)
         # ---------------- forward (eval)
-        y, am = _ops.conv_fwd(li, nbr, B, T, xd, wd, bd, 0.0, 0, True, ws)
+        y, am, _ = _ops.conv_fwd(li, nbr, B, T, xd, wd, bd, 0.0, 0, True, ws)
         torch.cuda.synchronize()
         close(y, y_ref, what=f"{name} fwd")
         if pool > 1:
@@ -83,7 +83,7 @@ def test_conv_layer(li, impl, T):
             assert int(am.max()) < pool
         # ---------------- forward (train): same mask as the numpy restatement of the hash
         seed = 4242
-        yt, _ = _ops.conv_fwd(li, nbr, B, T, xd, wd, bd, 0.1, seed, True, ws)
+        yt, _, spec = _ops.conv_fwd(li, nbr, B, T, xd, wd, bd, 0.1, seed, True, ws)
         keep = []
         for br in range(nbr):
             keep.append(dropout_ref.keep_mask(dropout_ref.layer_seed(seed, li, br), tuple(ys[br].shape), 0.1))
@@ -100,8 +100,8 @@ def test_conv_layer(li, impl, T):
         for br in range(nbr):
             close(dw[br], ws_cpu[br].grad, what=f"{name} wgrad br{br}")
             close(db[br], bs_cpu[br].grad, what=f"{name} bgrad br{br}")
-        # accumulate=True adds on top
-        _ops.conv_wgrad(li, nbr, B, T, dzd, xd, dw, db, True, ws)
+        # accumulate=True adds on top; this time hand over the input spectrum the forward call saved (if any)
+        _ops.conv_wgrad(li, nbr, B, T, dzd, xd, dw, db, True, ws, xspec=spec)
         close(dw[0], 2 * ws_cpu[0].grad, what=f"{name} wgrad accumulate")
         # ---------------- backward-data with fused ReLU/dropout mask + unpool of the previous layer
         if li > 0:
@@ -192,11 +192,11 @@ def test_unsupported_and_bad_arguments_fail_loudly():
     y = torch.zeros(1, 5, 8, 16, device=dev)
     ws = _ops.workspace(1 << 20, dev)
     rc = L.zns_conv2d_fwd_f32(1, 1, 16, 3, 5, 3, 3, 8, 1, x.data_ptr(), _ops._pp(w), _ops._pp(b), y.data_ptr(), None,
-                              0.0, 0, 0, ws.data_ptr(), ws.numel(), _ops.stream_ptr())
+                              0.0, 0, 0, None, ws.data_ptr(), ws.numel(), _ops.stream_ptr())
     assert rc == -1 and b"no gfx950 kernel instance" in L.zns_last_error()
     rc = L.zns_conv2d_fwd_f32(3, 1, 16, 1, 64, 3, 11, 96, 1, x.data_ptr(), _ops._pp(w), _ops._pp(b), y.data_ptr(),
-                              None, 0.0, 0, 0, ws.data_ptr(), ws.numel(), _ops.stream_ptr())
+                              None, 0.0, 0, 0, None, ws.data_ptr(), ws.numel(), _ops.stream_ptr())
     assert rc == -1
     rc = L.zns_conv2d_fwd_f32(1, 0, 16, 1, 64, 3, 11, 96, 1, x.data_ptr(), _ops._pp(w), _ops._pp(b), y.data_ptr(),
-                              None, 0.0, 0, 0, ws.data_ptr(), ws.numel(), _ops.stream_ptr())
+                              None, 0.0, 0, 0, None, ws.data_ptr(), ws.numel(), _ops.stream_ptr())
     assert rc == -1 and b"empty" in L.zns_last_error()

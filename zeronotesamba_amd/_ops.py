@@ -70,12 +70,18 @@ def conv_fwd(li: int, nbr: int, B: int, T: int, x: torch.Tensor, w: Sequence[tor
     am = None
     if pool > 1 and want_argmax:
         am = torch.empty((nbr * B, cout, H // pool, T), dtype=torch.uint8, device=x.device)
+    spec = None
+    if want_argmax:  # = activations are being saved for a backward pass: keep the input spectrum for backward-weights
+        nspec = _lib.lib().zns_conv2d_spectrum_bytes(nbr, B, T, cin, cout, kh, kw, H)
+        if nspec:
+            spec = torch.empty(nspec // 4, dtype=torch.float32, device=x.device)
     rc = _lib.lib().zns_conv2d_fwd_f32(nbr, B, T, cin, cout, kh, kw, H, pool, x.data_ptr(), _pp(w), _pp(b),
                                        y.data_ptr(), am.data_ptr() if am is not None else None,
                                        float(drop_p), int(seed) & 0xFFFFFFFF, li,
+                                       spec.data_ptr() if spec is not None else None,
                                        ws.data_ptr(), ws.numel(), stream_ptr())
     _lib.check(rc, f"zns_conv2d_fwd_f32[{name}]")
-    return y, am
+    return y, am, spec
 
 
 def conv_dgrad(li: int, nbr: int, B: int, T: int, dz: torch.Tensor, w: Sequence[torch.Tensor],
@@ -93,11 +99,14 @@ def conv_dgrad(li: int, nbr: int, B: int, T: int, dz: torch.Tensor, w: Sequence[
 
 
 def conv_wgrad(li: int, nbr: int, B: int, T: int, dz: torch.Tensor, x: torch.Tensor, dw: Sequence[torch.Tensor],
-               db: Sequence[torch.Tensor], accumulate: bool, ws: torch.Tensor) -> None:
+               db: Sequence[torch.Tensor], accumulate: bool, ws: torch.Tensor,
+               xspec: Optional[torch.Tensor] = None) -> None:
     name, cin, cout, kh, kw, pool = LAYERS[li]
     H = H_IN[li]
     rc = _lib.lib().zns_conv2d_wgrad_f32(nbr, B, T, cin, cout, kh, kw, H, dz.data_ptr(), x.data_ptr(), _pp(dw),
-                                         _pp(db), int(bool(accumulate)), ws.data_ptr(), ws.numel(), stream_ptr())
+                                         _pp(db), int(bool(accumulate)),
+                                         xspec.data_ptr() if xspec is not None else None,
+                                         ws.data_ptr(), ws.numel(), stream_ptr())
     _lib.check(rc, f"zns_conv2d_wgrad_f32[{name}]")
 
 
@@ -155,11 +164,13 @@ def stack_forward(x: torch.Tensor, P: StackParams, B: int, drop_p: float, seed: 
     argm: Dict[int, torch.Tensor] = {}
     cur = x
     for li in range(8):
-        y, am = conv_fwd(li, nbr, B, T, cur, P.conv_w[li], P.conv_b[li], drop_p, seed, save, ws)
+        y, am, spec = conv_fwd(li, nbr, B, T, cur, P.conv_w[li], P.conv_b[li], drop_p, seed, save, ws)
         if save:
             acts.append(y)
             if am is not None:
                 argm[li] = am
+            if spec is not None:
+                argm[100 + li] = spec   # input spectrum of layer li, reused by its backward-weights
         cur = y
     emb = head_fwd(nbr, B, T, cur, P.fc_w, P.fc_b) if with_head else None
     if not save:
@@ -190,7 +201,7 @@ def stack_backward(x: torch.Tensor, P: StackParams, B: int, acts: List[torch.Ten
         return
     for li in range(7, 0, -1):
         xin = acts[li - 1]
-        conv_wgrad(li, nbr, B, T, dz, xin, G.conv_w[li], G.conv_b[li], accumulate, ws)
+        conv_wgrad(li, nbr, B, T, dz, xin, G.conv_w[li], G.conv_b[li], accumulate, ws, argm.get(100 + li))
         if after_layer:
             after_layer(LAYERS[li][0])
         prev_pool = LAYERS[li - 1][5]

@@ -64,9 +64,14 @@ size_t zns_conv2d_workspace_bytes(int nbr, int B, int T, int cin, int cout, int 
     return (n + 255) & ~(size_t)255;
 }
 
+size_t zns_conv2d_spectrum_bytes(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H) {
+    ConvArgs a{nbr, B, T, cin, cout, kh, kw, H, 1};
+    return (g_impl == ZNS_IMPL_AUTO && fft_wgrad_supported(a)) ? fft_spectrum_bytes(a) : 0;
+}
+
 int zns_conv2d_fwd_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, int pool, const float* x,
                        const float* const* w, const float* const* bias, float* y, uint8_t* argmax, float drop_p,
-                       uint32_t seed, int layer, void* ws, size_t ws_bytes, void* stream) {
+                       uint32_t seed, int layer, float* xspec, void* ws, size_t ws_bytes, void* stream) {
     ConvArgs a{nbr, B, T, cin, cout, kh, kw, H, pool};
     int rc = check_conv(a, "conv2d_fwd");
     if (rc) return rc;
@@ -77,7 +82,7 @@ int zns_conv2d_fwd_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw,
     if (g_impl == ZNS_IMPL_NAIVE) return naive_fwd(a, x, pw, pb, y, argmax, drop_p, seed, layer, st);
     if (is_cv1(a) && pool == 1) return cv1_fwd(a, x, pw, pb, y, drop_p, seed, layer, st);
     if (g_impl == ZNS_IMPL_AUTO && fft_supported(a))
-        return fft_fwd(a, x, pw, pb, y, argmax, drop_p, seed, layer, ws, ws_bytes, st);
+        return fft_fwd(a, x, pw, pb, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
     if (mfma_supported(a)) return mfma_fwd(a, x, pw, pb, y, argmax, drop_p, seed, layer, ws, ws_bytes, st);
     set_error("conv2d_fwd: no gfx950 kernel instance for cin=%d cout=%d k=%dx%d H=%d", cin, cout, kh, kw, H);
     return ZNS_ERR_ARG;
@@ -102,8 +107,8 @@ int zns_conv2d_dgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int k
 }
 
 int zns_conv2d_wgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, const float* dz,
-                         const float* x, float* const* dw, float* const* db, int accumulate, void* ws,
-                         size_t ws_bytes, void* stream) {
+                         const float* x, float* const* dw, float* const* db, int accumulate, const float* xspec,
+                         void* ws, size_t ws_bytes, void* stream) {
     ConvArgs a{nbr, B, T, cin, cout, kh, kw, H, 1};
     int rc = check_conv(a, "conv2d_wgrad");
     if (rc) return rc;
@@ -117,7 +122,7 @@ int zns_conv2d_wgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int k
     }
     if (is_cv1(a)) return cv1_wgrad(a, dz, x, pdw, pdb, accumulate, ws, ws_bytes, st);
     if (g_impl == ZNS_IMPL_AUTO && fft_wgrad_supported(a))
-        return fft_wgrad(a, dz, x, pdw, pdb, accumulate, ws, ws_bytes, st);
+        return fft_wgrad(a, dz, x, pdw, pdb, accumulate, xspec, ws, ws_bytes, st);
     if (mfma_supported(a)) {
         rc = mfma_wgrad(a, dz, x, pdw, accumulate, ws, ws_bytes, st);
         if (rc) return rc;

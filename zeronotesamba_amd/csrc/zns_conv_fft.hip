@@ -431,6 +431,10 @@ static FftWs fft_ws(const ConvArgs& a) {
 }
 
 size_t fft_workspace_bytes(const ConvArgs& a) { return fft_supported(a) ? fft_ws(a).total : 0; }
+size_t fft_spectrum_bytes(const ConvArgs& a) {
+    const FftGeom g = geom(a);
+    return (size_t)g.nb * FS * a.cin * g.P * sizeof(float);
+}
 
 static int run_spec_fwd(const float* x, float* S, int nb, int C, int H, int T, const FftGeom& g, int off, int valid,
                         float third_sign, hipStream_t st) {
@@ -509,12 +513,12 @@ static int run_fconv(const ConvArgs& a, const FftGeom& g, Ptr2 w, int transposed
 
 template <class C>
 static int fft_fwd_t(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, uint8_t* argmax, float drop_p,
-                     uint32_t seed, int layer, void* ws, size_t ws_bytes, hipStream_t st) {
+                     uint32_t seed, int layer, float* xspec, void* ws, size_t ws_bytes, hipStream_t st) {
     const FftGeom g = geom(a);
     const FftWs L = fft_ws(a);
     if (ws_bytes < L.total) { set_error("conv fwd (fft): workspace %zu < %zu", ws_bytes, L.total); return ZNS_ERR_WORKSPACE; }
     char* base = (char*)ws;
-    float* s_in = (float*)(base + L.s_in);
+    float* s_in = xspec ? xspec : (float*)(base + L.s_in);   // kept by the caller for backward-weights when given
     float* s_out = (float*)(base + L.s_out);
     float* z = (float*)(base + L.z);
     float* wf = (float*)(base + L.wf);
@@ -560,8 +564,8 @@ static int fft_dgrad_t(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, co
 }
 
 template <class W>
-static int fft_wgrad_t(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, MPtr2 db, int accumulate, void* ws,
-                       size_t ws_bytes, hipStream_t st) {
+static int fft_wgrad_t(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, MPtr2 db, int accumulate,
+                       const float* xspec, void* ws, size_t ws_bytes, hipStream_t st) {
     const FftGeom g = geom(a);
     const FftWs L = fft_ws(a);
     if (ws_bytes < L.total) { set_error("conv wgrad (fft): workspace %zu < %zu", ws_bytes, L.total); return ZNS_ERR_WORKSPACE; }
@@ -569,7 +573,9 @@ static int fft_wgrad_t(const ConvArgs& a, const float* dz, const float* x, MPtr2
     float* sx = (float*)(base + L.s_in);
     float* sz = (float*)(base + L.s_out);
     float* slab = (float*)(base + L.slab);
-    int rc = run_spec_fwd(x, sx, g.nb, a.cin, a.H, a.T, g, a.kw / 2, FN, 1.f, st);   // windows of the input: (xr, xi, xr+xi)
+    int rc = ZNS_OK;
+    if (xspec) sx = const_cast<float*>(xspec);                                         // saved by the forward call
+    else rc = run_spec_fwd(x, sx, g.nb, a.cin, a.H, a.T, g, a.kw / 2, FN, 1.f, st);   // windows of the input: (xr, xi, xr+xi)
     if (rc) return rc;
     rc = run_spec_fwd(dz, sz, g.nb, a.cout, a.H, a.T, g, 0, g.V, -1.f, st);     // zero-padded V-blocks of dZ: (r, i, r-i)
     if (rc) return rc;
@@ -604,13 +610,13 @@ static int fft_wgrad_t(const ConvArgs& a, const float* dz, const float* x, MPtr2
 }
 
 int fft_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, uint8_t* argmax, float drop_p,
-            uint32_t seed, int layer, void* ws, size_t ws_bytes, hipStream_t st) {
+            uint32_t seed, int layer, float* xspec, void* ws, size_t ws_bytes, hipStream_t st) {
     switch (fft_layer_of(a)) {
-        case 2: return fft_fwd_t<FF2>(a, x, w, bias, y, argmax, drop_p, seed, layer, ws, ws_bytes, st);
-        case 3: return fft_fwd_t<FF3>(a, x, w, bias, y, argmax, drop_p, seed, layer, ws, ws_bytes, st);
-        case 4: return fft_fwd_t<FF4>(a, x, w, bias, y, argmax, drop_p, seed, layer, ws, ws_bytes, st);
-        case 5: return fft_fwd_t<FF5>(a, x, w, bias, y, argmax, drop_p, seed, layer, ws, ws_bytes, st);
-        case 6: return fft_fwd_t<FF6>(a, x, w, bias, y, argmax, drop_p, seed, layer, ws, ws_bytes, st);
+        case 2: return fft_fwd_t<FF2>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
+        case 3: return fft_fwd_t<FF3>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
+        case 4: return fft_fwd_t<FF4>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
+        case 5: return fft_fwd_t<FF5>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
+        case 6: return fft_fwd_t<FF6>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
     }
     return ZNS_ERR_ARG;
 }
@@ -627,14 +633,14 @@ int fft_dgrad(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, const float
     return ZNS_ERR_ARG;
 }
 
-int fft_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, MPtr2 db, int accumulate, void* ws,
-              size_t ws_bytes, hipStream_t st) {
+int fft_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, MPtr2 db, int accumulate,
+              const float* xspec, void* ws, size_t ws_bytes, hipStream_t st) {
     switch (fft_layer_of(a)) {
-        case 2: return fft_wgrad_t<FW2>(a, dz, x, dw, db, accumulate, ws, ws_bytes, st);
-        case 3: return fft_wgrad_t<FW3>(a, dz, x, dw, db, accumulate, ws, ws_bytes, st);
-        case 4: return fft_wgrad_t<FW4>(a, dz, x, dw, db, accumulate, ws, ws_bytes, st);
-        case 5: return fft_wgrad_t<FW5>(a, dz, x, dw, db, accumulate, ws, ws_bytes, st);
-        case 6: return fft_wgrad_t<FW6>(a, dz, x, dw, db, accumulate, ws, ws_bytes, st);
+        case 2: return fft_wgrad_t<FW2>(a, dz, x, dw, db, accumulate, xspec, ws, ws_bytes, st);
+        case 3: return fft_wgrad_t<FW3>(a, dz, x, dw, db, accumulate, xspec, ws, ws_bytes, st);
+        case 4: return fft_wgrad_t<FW4>(a, dz, x, dw, db, accumulate, xspec, ws, ws_bytes, st);
+        case 5: return fft_wgrad_t<FW5>(a, dz, x, dw, db, accumulate, xspec, ws, ws_bytes, st);
+        case 6: return fft_wgrad_t<FW6>(a, dz, x, dw, db, accumulate, xspec, ws, ws_bytes, st);
     }
     return ZNS_ERR_ARG;
 }
