@@ -104,3 +104,43 @@ def test_dropout_rate_and_accumulation_full_size():
         _ops.stack_backward(x, P, B, acts, argm, emb, demb, None, 1.0, _ops.StackParams.from_flat(g2, 2), accumulate=True)
     for u, v in zip(g1, g2):
         assert ((v - 2 * u).norm() / u.norm().clamp_min(1e-30)).item() < 1e-6
+
+
+def test_finetune_shape_long_clip_direct_path():
+    """BASELINE config 4 shape: batch of one 30 s clip (T=1876, epochs.py:48-63).  Too many windows per row for the
+    frequency-domain kernels, so this exercises the direct MFMA kernels at a long, non-multiple-of-32 T."""
+    from zeronotesamba_amd import _lib
+    B, T = 1, 1876
+    model = build(3)
+    x = synth(B, T, 4)
+    e_a, _, g_a = run(_lib.ZNS_IMPL_AUTO, model, x, B)
+    e_n, _, _ = run(_lib.ZNS_IMPL_NAIVE, model, x, B, backward=False)
+    assert tuple(e_a.shape) == (2, T)
+    assert (e_a - e_n).abs().max().item() < 1e-4
+    assert all(torch.isfinite(g).all().item() for g in g_a)
+
+
+def test_clmr_style_shared_branch_module_api():
+    """pretext.py:494-511 ("clmr"): ONE DS_CNN applied to two views; its weight gradient is the sum of both passes."""
+    from zeronotesamba_amd.models.loss_functions import NTXent
+    from zeronotesamba_amd.models.models import DS_CNN
+    torch.manual_seed(0)
+    m = DS_CNN().to(DEV).eval()
+    B, T = 4, 64
+    v = synth(B, T, 5)
+    a = m(v[:B])
+    p = m(v[B:])
+    loss, _, _ = NTXent(B, 0.25)(a, p)
+    loss.backward()
+    g_both = m.pretrained.cv3.weight.grad.clone()
+    m.zero_grad()
+    a = m(v[:B])
+    loss2, _, _ = NTXent(B, 0.25)(a, p.detach())
+    loss2.backward()
+    g_a = m.pretrained.cv3.weight.grad.clone()
+    m.zero_grad()
+    p = m(v[B:])
+    loss3, _, _ = NTXent(B, 0.25)(a.detach(), p)
+    loss3.backward()
+    g_p = m.pretrained.cv3.weight.grad.clone()
+    assert ((g_both - (g_a + g_p)).norm() / g_both.norm()).item() < 1e-5

@@ -1,0 +1,107 @@
+"""GPU: the fused PretextTrainer (flat buffers, no autograd) against the drop-in module path with a stock
+torch.optim.Adam -- i.e. the reference's own step structure (pretext.py:475-492) -- plus the epoch functions,
+the fused Adam and the on-device shift batching (pretext.py:308-318)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cnn_ref  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def make_model(seed=5):
+    from zeronotesamba_amd.models.models import Pretext_CNN
+    m = Pretext_CNN()
+    m.load_state_dict(cnn_ref.synth_state_dict(seed, 2.0))
+    return m.to(DEV)
+
+
+def test_trainer_step_equals_module_path():
+    """Same kernels through two host paths: gradients must be bitwise equal, losses equal."""
+    from zeronotesamba_amd.models.loss_functions import NTXent
+    from zeronotesamba_amd.pretext import PretextTrainer
+    B, T, tau, lr = 4, 64, 0.25, 1e-4
+    ma, mb = make_model(), make_model()
+    ma.eval()
+    tr = PretextTrainer(mb, batch_len=B, temperature=tau, lr=lr, train=False)
+    crit = NTXent(B, tau)
+    batch = cnn_ref.synth_vqt(200, (B, 2, 96, T))
+    a, p = ma(batch[:, 0:1].to(DEV), batch[:, 1:2].to(DEV))
+    loss, cp, cn = crit(a, p)
+    loss.backward()
+    out3 = tr.step(tr.stack_inputs(batch), update=False).tolist()
+    assert abs(out3[0] - loss.item()) < 1e-6 and abs(out3[1] - cp) < 1e-6 and abs(out3[2] - cn) < 1e-6
+    for (ka, va), (kb, vb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert ka == kb
+        assert torch.equal(va.grad, vb.grad), ka
+    # the trainer keeps module parameters as views of its flat buffer: state_dict still round-trips
+    sd = mb.state_dict()
+    assert sd["anchor.pretrained.cv4.weight"].data_ptr() == mb.anchor.pretrained.cv4.weight.data_ptr()
+    # and one update moves every parameter by at most lr (Adam's first step is sign-like)
+    before = tr.flat_p.clone()
+    tr.step(tr.stack_inputs(batch))
+    d = (tr.flat_p - before).abs()
+    assert d.max().item() <= lr * 1.001 and d.mean().item() > 0.5 * lr
+
+
+def test_fused_adam_matches_torch_adam():
+    """zns_adam_step_f32 against torch.optim.Adam on well-conditioned gradients (|g| >> eps)."""
+    from zeronotesamba_amd.optim import Adam
+    g = torch.Generator().manual_seed(0)
+    p0 = torch.randn(100003, generator=g)
+    pa = p0.clone().to(DEV).requires_grad_(True)
+    pb = p0.clone().to(DEV).requires_grad_(True)
+    oa, ob = torch.optim.Adam([pa], lr=1e-3), Adam([pb], lr=1e-3)
+    for _ in range(5):
+        gr = torch.randn(100003, generator=g).to(DEV)
+        pa.grad, pb.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+    assert (pa - pb).abs().max().item() < 2e-6
+    with pytest.raises(ValueError):
+        Adam([pb], lr=1e-3, weight_decay=0.1)
+
+
+def test_epoch_functions_and_fused_adam():
+    from zeronotesamba_amd.models.loss_functions import NTXent
+    from zeronotesamba_amd.optim import Adam
+    from zeronotesamba_amd.pretext import PretextTrainer, train_epoch, val_epoch
+    B, T = 4, 40
+    loader = [[cnn_ref.synth_vqt(300 + i, (B, 2, 96, T))] for i in range(2)]
+    m1, m2 = make_model(7), make_model(7)
+    crit = NTXent(B, 0.25)
+    torch.manual_seed(3)
+    m1, l1, p1, n1 = train_epoch(m1, loader, crit, torch.optim.Adam(m1.parameters(), lr=1e-5))
+    torch.manual_seed(3)
+    m2, l2, p2, n2 = train_epoch(m2, loader, crit, Adam(m2.parameters(), lr=1e-5))
+    assert abs(l1 - l2) < 1e-5 and abs(p1 - p2) < 1e-5 and abs(n1 - n2) < 1e-5
+    for va, vb in zip(m1.parameters(), m2.parameters()):
+        assert (va - vb).abs().max().item() <= 2.1 * 1e-5   # two sign-like steps of lr each, |g| ~ eps elements may differ
+    vl, vp, vn = val_epoch(m1, loader, crit, None)
+    assert np.isfinite([vl, vp, vn]).all() and 0 < vp <= 1.0
+    with pytest.raises(ValueError, match="Which pretext task"):
+        train_epoch(m1, loader, crit, None, pt_task="nope")
+    tr = PretextTrainer(make_model(8), batch_len=B, lr=1e-6)
+    tl, tp, tn = tr.train_epoch(loader)
+    assert np.isfinite([tl, tp, tn]).all()
+    with pytest.raises(IndexError):
+        tr.step(torch.zeros(2 * (B + 1), 1, 96, T, device=DEV))
+
+
+def test_shift_gather_matches_reference_indexing():
+    """pretext.py:312-318: 16 distinct starts in range(313), 313-frame crops of one 626-frame bank row."""
+    from zeronotesamba_amd import _lib, _ops
+    rng = np.random.default_rng(0)
+    bank = torch.from_numpy(rng.standard_normal((3, 2, 96, 626)).astype(np.float32)).to(DEV)
+    starts = rng.choice(313, size=16, replace=False).astype(np.int32)
+    clip = np.full(16, 1, dtype=np.int32)
+    out = torch.empty((2, 16, 96, 313), dtype=torch.float32, device=DEV)
+    clip_d, starts_d = torch.from_numpy(clip).to(DEV), torch.from_numpy(starts).to(DEV)   # keep alive across the call
+    rc = _lib.lib().zns_shift_gather_f32(bank.data_ptr(), 626, clip_d.data_ptr(), starts_d.data_ptr(), 16, 313,
+                                         out.data_ptr(), _ops.stream_ptr())
+    _lib.check(rc, "shift_gather")
+    ref = torch.stack([bank[1, :, :, s:s + 313] for s in starts], dim=0)      # [16, 2, 96, 313] as new_train_bank rows
+    assert torch.equal(out, ref.transpose(0, 1).contiguous())
