@@ -49,7 +49,10 @@ def spectral_flop(layer: str, useful: bool) -> float:
 EXEC_FLOP = 3 * sum(spectral_flop(l, False) for l in LAYER_GEOM) + 3 * 2 * 2 * B * (MACS["cv7"] + MACS["cv8"])
 # dominant kernel (profiles/): the frequency-domain forward GEMM-conv of cv4 (conv_core<256,256,1x9 taps>)
 PROBE = dict(kind=0, cin=128, cout=128, kh=9, name="conv_core<spectral cv4 forward: 96 real 128x1152 GEMM-convs per sample, 9 row taps>",
-             flop=spectral_flop("cv4", True))
+             flop=spectral_flop("cv4", True),
+             # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/r01_final_pmc_summary.csv):
+             # FETCH_SIZE 602 449 KB x 2 (gfx950 counts the 128-B requests of 16-byte loads as 64 B) + WRITE_SIZE 540 672 KB
+             traffic=(2 * 602449 + 540672) * 1024.0)
 
 
 def synth_batch(seed: int, device) -> torch.Tensor:
@@ -190,7 +193,7 @@ def main():
                        "executed_frac_of_fp32_mfma_peak": (EXEC_FLOP * K / dt) / (FP32_MFMA_PEAK_TFLOPS * 1e12),
                        "last_loss": float(out[0].item())},
             "roofline": {"bound": "mfma", "kernel": PROBE["name"], "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": PROBE["traffic"],
                          "kernel_ms": kavg, "launches_timed": len(kms)},
         }
         if world == 1 and not args.no_cpu_baseline:
