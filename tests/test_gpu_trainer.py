@@ -105,3 +105,47 @@ def test_shift_gather_matches_reference_indexing():
     _lib.check(rc, "shift_gather")
     ref = torch.stack([bank[1, :, :, s:s + 313] for s in starts], dim=0)      # [16, 2, 96, 313] as new_train_bank rows
     assert torch.equal(out, ref.transpose(0, 1).contiguous())
+
+
+def test_shift_bank_sampler_and_fused_epoch():
+    """Resident bank + on-device crops follow the reference's sampling law and batch grouping (pretext.py:308-321)."""
+    import random
+    from zeronotesamba_amd.pretext import PretextTrainer, ShiftBank
+    rng = np.random.default_rng(1)
+    bank_np = rng.standard_normal((3, 2, 96, 626)).astype(np.float32)
+    sb = ShiftBank(bank_np, batch_len=16, crop=313, device=DEV)
+    random.seed(5)
+    expect = random.sample(range(0, 313), 16)                       # what the reference would draw
+    random.seed(5)
+    x = sb.batch(2)
+    assert tuple(x.shape) == (32, 1, 96, 313)
+    ref = np.stack([bank_np[2, :, :, s:s + 313] for s in expect])   # rows of new_train_bank for clip 2
+    np.testing.assert_array_equal(x[:16, 0].cpu().numpy(), ref[:, 0])
+    np.testing.assert_array_equal(x[16:, 0].cpu().numpy(), ref[:, 1])
+    assert len(set(expect)) == 16 and max(expect) < 313
+    with pytest.raises(IndexError):
+        sb.batch(3)
+    with pytest.raises(ValueError):
+        sb.batch(0, starts=[0] * 15)
+    tr = PretextTrainer(make_model(9), batch_len=16, lr=1e-6)
+    l, p, n = tr.train_epoch(sb.batches([0, 1], rng=random.Random(3)))
+    assert np.isfinite([l, p, n]).all()
+
+
+def test_load_models_rules():
+    """loader.py:8-69: checkpoint loading, freezing and learning-rate rules."""
+    from zeronotesamba_amd.loader import load_models
+    sd = cnn_ref.synth_state_dict(7, 2.0)
+    crit, opt, model = load_models("pretrained", "frozen", 1e-5, state_dict=sd)
+    assert not any(p.requires_grad for p in model.pretext.anchor.pretrained.parameters())
+    assert all(p.requires_grad for p in model.pretext.anchor.fc1.parameters())
+    assert sum(len(g["params"]) for g in opt.param_groups) == 4 and opt.param_groups[0]["lr"] == 1e-5
+    crit, opt, model = load_models("pretrained", "finetune", 1e-5, state_dict=sd)
+    assert abs(opt.param_groups[0]["lr"] - 0.5 * 1e-5 * 10e-2) < 1e-18 and len(opt.param_groups[0]["params"]) == 36
+    x = cnn_ref.synth_vqt(300, (2, 96, 40))
+    out = model(x[0].reshape(1, 1, 96, 40).to(DEV), x[1].reshape(1, 1, 96, 40).to(DEV))
+    loss = crit(out, torch.full_like(out, 0.5))
+    loss.backward()
+    opt.step()
+    crit, opt, model = load_models("vanilla", "", 1e-4)
+    assert type(model).__name__ == "DS_CNN" and opt.param_groups[0]["lr"] == 1e-4

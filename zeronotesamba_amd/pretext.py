@@ -94,6 +94,59 @@ def _loss_and_stats(criterion: NTXent, a: torch.Tensor, p: torch.Tensor):
     return loss, stats
 
 
+class ShiftBank:
+    """Resident memory bank + on-device shift batching (pretext.py:255-263, 285-292, 308-321).
+
+    The reference materialises `new_train_bank` on the host: for every clip it draws `batch_len` DISTINCT start
+    frames with `random.sample(range(0, 313), batch_len)` and copies 313-frame crops of the 626-frame bank row
+    (5.5 GB of host memcpy per sub-epoch).  Here the `(N, 2, 96, 626)` bank lives in HBM (28 800 clips = 13.8 GB)
+    and one gather kernel cuts the 16 crops of a clip straight into the branch-major layout the twin launch
+    consumes.  Same sampling law (Python's `random.sample`, so `random.seed` reproduces the reference's draws),
+    same "one clip per batch, order preserved" grouping (DataLoader(shuffle=False), pretext.py:320-321).
+    """
+
+    def __init__(self, bank, batch_len: int = 16, crop: int = 313, device: str = "cuda"):
+        b = torch.as_tensor(bank, dtype=torch.float32)
+        if b.dim() != 4 or b.shape[1] != 2 or b.shape[2] != _ops.N_BINS:
+            raise ValueError(f"bank must be (N, 2, 96, T), got {tuple(b.shape)}")
+        if b.shape[3] - crop < batch_len:
+            raise ValueError("not enough distinct start frames for batch_len crops")
+        self.bank = b.to(device).contiguous()
+        self.batch_len, self.crop = batch_len, crop
+        self.n_clips, self.bank_T = b.shape[0], b.shape[3]
+
+    def shuffle_(self, generator: Optional[torch.Generator] = None) -> None:
+        """np.random.shuffle(train_bank) (pretext.py:282), on the device."""
+        perm = torch.randperm(self.n_clips, generator=generator).to(self.bank.device)
+        self.bank = self.bank[perm].contiguous()
+
+    def draw_starts(self, rng=None) -> List[int]:
+        import random as _random
+        r = rng if rng is not None else _random
+        return r.sample(range(0, self.bank_T - self.crop), self.batch_len)      # pretext.py:312
+
+    def batch(self, clip: int, starts: Optional[Sequence[int]] = None, rng=None) -> torch.Tensor:
+        """The 16 shifted crops of `clip`, branch-major [2*batch_len, 1, 96, crop] (anchors first)."""
+        if not 0 <= clip < self.n_clips:
+            raise IndexError(f"clip {clip} out of range [0, {self.n_clips})")
+        if starts is None:
+            starts = self.draw_starts(rng)
+        if len(starts) != self.batch_len or min(starts) < 0 or max(starts) + self.crop > self.bank_T:
+            raise ValueError("bad start frames")
+        dev = self.bank.device
+        idx = torch.tensor([[clip] * self.batch_len, list(starts)], dtype=torch.int32).to(dev, non_blocking=True)
+        out = torch.empty((2 * self.batch_len, 1, _ops.N_BINS, self.crop), dtype=torch.float32, device=dev)
+        rc = _lib.lib().zns_shift_gather_f32(self.bank.data_ptr(), self.bank_T, idx[0].data_ptr(), idx[1].data_ptr(),
+                                             self.batch_len, self.crop, out.data_ptr(), _ops.stream_ptr())
+        _lib.check(rc, "zns_shift_gather_f32")
+        self._keep = idx     # the index tensor must outlive the enqueued kernel
+        return out
+
+    def batches(self, clips: Iterable[int], rng=None):
+        for c in clips:
+            yield self.batch(int(c), rng=rng)
+
+
 class PretextTrainer:
     """Fused pretext step over flat parameter / gradient / moment buffers (see module docstring)."""
 
@@ -215,11 +268,14 @@ class PretextTrainer:
         return out3
 
     def train_epoch(self, loader: Iterable) -> Tuple[float, float, float]:
-        """Fused equivalent of pretext.train_epoch: returns (mean loss, mean pos cos, mean neg cos)."""
+        """Fused equivalent of pretext.train_epoch: returns (mean loss, mean pos cos, mean neg cos).
+        `loader` yields either the reference's `[batch]` with batch [B,2,96,T] (DataLoader over a TensorDataset) or
+        branch-major device tensors [2B,1,96,T] (ShiftBank.batches)."""
         acc = torch.zeros(3, dtype=torch.float64, device=self.flat_p.device)
         n = 0
-        for [batch] in loader:
-            acc += self.step(self.stack_inputs(batch)).double()
+        for item in loader:
+            x = item if torch.is_tensor(item) else self.stack_inputs(item[0])
+            acc += self.step(x).double()
             n += 1
         l, p, ng = (acc / max(n, 1)).tolist()
         return l, p, ng
