@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""generate_XQT throughput (BASELINE config 2): n_clips x 160 000 samples -> n_clips x 96 x 626, inputs resident in HBM.
+Reports clips/s and achieved GB/s against the algorithmic bytes (640 KB in + 240 KB out per clip)."""
+import sys, os, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from zeronotesamba_amd.processing.input_rep import generate_XQT_batch
+
+def run(n_clips, iters):
+    g = torch.Generator().manual_seed(1234)
+    y = (0.1 * torch.randn(n_clips, 160000, generator=g)).cuda()
+    for _ in range(2):
+        out = generate_XQT_batch(y, 16000, "vqt")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        out = generate_XQT_batch(y, 16000, "vqt")
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    alg = n_clips * (160000 * 4 + 96 * 626 * 4)
+    return {"n_clips": n_clips, "ms": dt * 1e3, "clips_per_s": n_clips / dt, "algorithmic_GBps": alg / dt / 1e9,
+            "frac_of_8TBps": alg / dt / 8e12}
+
+if __name__ == "__main__":
+    for n, it in ((32, 50), (512, 10), (4096, 3)):
+        print(json.dumps(run(n, it)))

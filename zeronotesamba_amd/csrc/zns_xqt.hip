@@ -28,12 +28,17 @@ constexpr double KF_ROLLOFF = 0.85, KF_BETA = 8.555504641634386;
 constexpr double HANN_BW = 1.50018310546875;
 constexpr int NL = 32, NR = 31;   // decimation taps touched for the exact 2:1 ratio
 
+struct DecTaps {
+    double l[NL];   // taps applied to x[2t - i]
+    double r[NR];   // taps applied to x[2t + 1 + k]
+};
+
 struct Bank {
     int n_fft[XQ_OCT];
     int hop[XQ_OCT];
     int off[XQ_OCT];        // float2 offset of octave i inside `fir`
-    float2* fir = nullptr;  // device: [octave][12][n_fft] complex
-    double* taps = nullptr; // device: left[32] then right[31]
+    float2* fir = nullptr;  // device: [octave][n_fft][12] complex (tap-major: one frame step reads 12 neighbours)
+    DecTaps* taps = nullptr;   // device: float64 decimation taps
     bool ready = false;
 };
 Bank g_bank[2];
@@ -154,12 +159,16 @@ int ensure_bank(int mode, Bank** out) {
         }
         std::vector<float2> h(total);
         for (int i = 0; i < XQ_OCT; ++i)
-            for (size_t j = 0; j < fir[i].size(); ++j) h[b.off[i] + j] = make_float2((float)fir[i][j].real(), (float)fir[i][j].imag());
+            for (int k = 0; k < XQ_BPO; ++k)
+                for (int j = 0; j < b.n_fft[i]; ++j) {
+                    const std::complex<double> c = fir[i][(size_t)k * b.n_fft[i] + j];
+                    h[b.off[i] + (size_t)j * XQ_BPO + k] = make_float2((float)c.real(), (float)c.imag());
+                }
         double taps[NL + NR];
         build_taps(taps, taps + NL);
         ZNS_HIP(hipMalloc(&b.fir, total * sizeof(float2)));
-        ZNS_HIP(hipMalloc(&b.taps, sizeof(taps)));
         ZNS_HIP(hipMemcpy(b.fir, h.data(), total * sizeof(float2), hipMemcpyHostToDevice));
+        ZNS_HIP(hipMalloc(&b.taps, sizeof(DecTaps)));
         ZNS_HIP(hipMemcpy(b.taps, taps, sizeof(taps), hipMemcpyHostToDevice));
         b.ready = true;
     }
@@ -182,30 +191,58 @@ void pyramid(int n, int* len, size_t* off) {
 
 }  // namespace
 
-// one thread per output sample; exact restatement of resampy's float32 tap-by-tap accumulation
-__global__ void decimate2_kernel(const float* __restrict__ in, long long in_stride, int n_in,
-                                 float* __restrict__ out, long long out_stride, int n_out_fix,
-                                 const double* __restrict__ taps, int n_clips) {
+
+// thread -> 4 consecutive outputs of one clip.  The 72-sample input window is fetched once (18 aligned 16-byte
+// loads when the rows allow it) and kept in registers as float64; the 63 float64 taps are wave-uniform (scalar
+// cache).  Exact restatement of resampy's accumulation: y (float32) += weight (float64) * x, i.e. the float64
+// product-sum is rounded to float32 after EVERY tap, left wing i = 0..31 first, then the right wing.
+__global__ void __launch_bounds__(256) decimate2_kernel(const float* __restrict__ in, long long in_stride, int n_in,
+                                                        float* __restrict__ out, long long out_stride, int n_quads,
+                                                        const DecTaps* __restrict__ tp, int n_clips, int vec_ok) {
     const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= (long long)n_clips * n_out_fix) return;
-    const int t = (int)(o % n_out_fix), c = (int)(o / n_out_fix);
+    if (o >= (long long)n_clips * n_quads) return;
+    const int q = (int)(o % n_quads), c = (int)(o / n_quads);
     const float* x = in + (long long)c * in_stride;
+    const int t0 = q * 4;
     const int n_out = n_in / 2;   // resampy: int(n * 0.5); librosa pads to ceil with zeros
-    float acc = 0.f;
-    if (t < n_out) {
-        const int n = 2 * t;
-#pragma unroll 4
-        for (int i = 0; i < NL; ++i) {
-            const int idx = n - i;
-            if (idx >= 0) acc = (float)((double)acc + taps[i] * (double)x[idx]);
+    const int base = 2 * t0 - 32; // xw[j] = x[base + j]
+    double xw[72];
+    if (vec_ok) {
+#pragma unroll
+        for (int v = 0; v < 18; ++v) {
+            const int i0 = base + 4 * v;
+            float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i0 >= 0 && i0 < n_in) f = *reinterpret_cast<const float4*>(x + i0);
+            xw[4 * v + 0] = (double)f.x;
+            xw[4 * v + 1] = (i0 + 1 < n_in) ? (double)f.y : 0.0;
+            xw[4 * v + 2] = (i0 + 2 < n_in) ? (double)f.z : 0.0;
+            xw[4 * v + 3] = (i0 + 3 < n_in) ? (double)f.w : 0.0;
         }
-#pragma unroll 4
-        for (int k = 0; k < NR; ++k) {
-            const int idx = n + k + 1;
-            if (idx < n_in) acc = (float)((double)acc + taps[NL + k] * (double)x[idx]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 72; ++j) {
+            const int i0 = base + j;
+            xw[j] = (i0 >= 0 && i0 < n_in) ? (double)x[i0] : 0.0;
         }
     }
-    out[(long long)c * out_stride + t] = acc / 0.70710677f;   // y_hat /= sqrt(0.5) in float32
+    // a tap outside the signal contributes w * 0 = +0: identical to resampy skipping it
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};   // always holds a float32-representable value
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const double w = tp->l[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = (double)(float)(acc[k] + w * xw[32 + 2 * k - i]);
+    }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const double w = tp->r[j];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = (double)(float)(acc[k] + w * xw[32 + 2 * k + 1 + j]);
+    }
+    float y[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) y[k] = (t0 + k < n_out) ? (float)acc[k] / 0.70710677f : 0.f;   // y_hat /= sqrt(0.5) in float32
+    *reinterpret_cast<float4*>(out + (long long)c * out_stride + t0) = make_float4(y[0], y[1], y[2], y[3]);
 }
 
 struct XqtLevels {
@@ -217,37 +254,91 @@ struct XqtLevels {
     int off[XQ_OCT];
 };
 
-// block: 128 consecutive frames of one (octave, clip); filters of the octave staged in LDS (broadcast reads)
-__global__ void __launch_bounds__(128) xqt_filter_kernel(XqtLevels L, const float2* __restrict__ fir, int n_frames,
+constexpr int XQ_FPB = 64;   // frames per block
+constexpr int XQ_GRP = 4;    // filter groups per block (3 filters each): 256 threads
+
+struct TapChunk {
+    float2 c[4][3];   // 4 consecutive taps x 3 filters, wave-uniform
+};
+
+__device__ __forceinline__ void load_taps(TapChunk& d, const float2* __restrict__ g) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d.c[j][k] = g[j * XQ_BPO + k];
+}
+
+__device__ __forceinline__ void apply_taps(const TapChunk& tc, const float* x, float* re, float* im) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            re[k] = fmaf(tc.c[j][k].x, x[j], re[k]);
+            im[k] = fmaf(tc.c[j][k].y, x[j], im[k]);
+        }
+}
+
+// block: 64 consecutive frames of one (octave, clip); 256 threads = 64 frames x 4 groups of 3 filters.
+// The frames' windows are staged into LDS with coalesced loads, 8 in flight per thread (row stride n_fft + 1:
+// conflict-free per-frame reads).  The filter taps are wave-uniform: they stream through the scalar cache from the
+// tap-major [n][12] device layout, one 4-tap chunk ahead of the FMAs (the x values are fetched from LDS one chunk
+// ahead too, because LDS and scalar loads share a wait counter).
+__global__ void __launch_bounds__(256) xqt_filter_kernel(XqtLevels L, const float2* __restrict__ fir, int n_frames,
                                                          float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float2 sfir[];
+    extern __shared__ __attribute__((aligned(16))) float rows[];
     const int oct = blockIdx.y, clip = blockIdx.z;
     const int n_fft = L.n_fft[oct], hop = L.hop[oct], len = L.len[oct];
-    for (int i = threadIdx.x; i < XQ_BPO * n_fft; i += blockDim.x) sfir[i] = fir[L.off[oct] + i];
-    __syncthreads();
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_frames) return;
+    const int lg = 31 - __builtin_clz(n_fft);
+    const int f0 = blockIdx.x * XQ_FPB;
     const float* y = L.y[oct] + (long long)clip * L.stride[oct];
-    float re[XQ_BPO], im[XQ_BPO];
+    const int rs = n_fft + 1;
+    // XQ_FPB * n_fft is a multiple of 256 * 4 (n_fft >= 16)
+    for (int i0 = threadIdx.x; i0 < XQ_FPB * n_fft; i0 += 256 * 4) {
+        float v[4];
 #pragma unroll
-    for (int k = 0; k < XQ_BPO; ++k) { re[k] = 0.f; im[k] = 0.f; }
-    const int start = t * hop - n_fft / 2;
-    for (int n = 0; n < n_fft; ++n) {
-        int idx = start + n;
-        if (idx < 0) idx = -idx;                       // np.pad(mode="reflect")
-        if (idx >= len) idx = 2 * (len - 1) - idx;
-        const float x = y[idx];
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 256;
+            const int f = i >> lg, n = i & (n_fft - 1);
+            int idx = (f0 + f) * hop - n_fft / 2 + n;
+            if (idx < 0) idx = -idx;                       // np.pad(mode="reflect")
+            if (idx >= len) idx = 2 * (len - 1) - idx;
+            idx = idx < 0 ? 0 : idx;                       // frames past the end are never written out
+            v[u] = (f0 + f < n_frames) ? y[idx] : 0.f;
+        }
 #pragma unroll
-        for (int k = 0; k < XQ_BPO; ++k) {
-            const float2 g = sfir[k * n_fft + n];
-            re[k] = fmaf(g.x, x, re[k]);
-            im[k] = fmaf(g.y, x, im[k]);
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 256;
+            rows[(i >> lg) * rs + (i & (n_fft - 1))] = v[u];
         }
     }
-    const int k0 = XQ_BINS - XQ_BPO * (oct + 1);
+    __syncthreads();
+    const int f = threadIdx.x & 63;
+    const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float2* gf = fir + L.off[oct] + g * 3;
+    const float* xr = rows + f * rs;
+    float re[3] = {0.f, 0.f, 0.f}, im[3] = {0.f, 0.f, 0.f};
+    TapChunk ta, tb;
+    float xa[4], xb[4];
+    load_taps(ta, gf);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xa[j] = xr[j];
+    for (int n = 0; n < n_fft; n += 8) {   // n_fft is a power of two >= 16
+        load_taps(tb, gf + (n + 4) * XQ_BPO);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xb[j] = xr[n + 4 + j];
+        apply_taps(ta, xa, re, im);
+        const int nn = (n + 8 < n_fft) ? n + 8 : 0;   // last prefetch wraps to a valid address, result unused
+        load_taps(ta, gf + nn * XQ_BPO);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xa[j] = xr[nn + j];
+        apply_taps(tb, xb, re, im);
+    }
+    const int t = f0 + f;
+    if (t >= n_frames) return;
+    const int k0 = XQ_BINS - XQ_BPO * (oct + 1) + g * 3;
     float* o = out + ((size_t)clip * XQ_BINS + k0) * n_frames + t;
 #pragma unroll
-    for (int k = 0; k < XQ_BPO; ++k) o[(size_t)k * n_frames] = logf(sqrtf(re[k] * re[k] + im[k] * im[k]) + 1e-9f);
+    for (int k = 0; k < 3; ++k) o[(size_t)k * n_frames] = logf(sqrtf(re[k] * re[k] + im[k] * im[k]) + 1e-9f);
 }
 
 }  // namespace zns
@@ -327,16 +418,18 @@ int zns_xqt_f32(const float* wav, int n_clips, int n_samples, int sample_rate, i
         }
     }
     for (int i = 1; i < XQ_OCT; ++i) {
-        const long long total = (long long)n_clips * len[i];
+        const int n_quads = (len[i] + 3) / 4;
+        const long long total = (long long)n_clips * n_quads;
+        const int vec_ok = (L.stride[i - 1] % 4 == 0) && ((uintptr_t)L.y[i - 1] % 16 == 0);
         hipLaunchKernelGGL(decimate2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, L.y[i - 1],
-                           L.stride[i - 1], len[i - 1], (float*)L.y[i], L.stride[i], len[i], b->taps, n_clips);
+                           L.stride[i - 1], len[i - 1], (float*)L.y[i], L.stride[i], n_quads, b->taps, n_clips, vec_ok);
         ZNS_LAUNCH_CHECK();
     }
     const int n_frames = zns_xqt_frames(n_samples);
     int max_fft = 0;
     for (int i = 0; i < XQ_OCT; ++i) max_fft = std::max(max_fft, b->n_fft[i]);
-    const size_t lds = (size_t)XQ_BPO * max_fft * sizeof(float2);
-    hipLaunchKernelGGL(xqt_filter_kernel, dim3((n_frames + 127) / 128, XQ_OCT, n_clips), dim3(128), lds, st, L, b->fir,
+    const size_t lds = (size_t)XQ_FPB * (max_fft + 1) * sizeof(float);
+    hipLaunchKernelGGL(xqt_filter_kernel, dim3((n_frames + XQ_FPB - 1) / XQ_FPB, XQ_OCT, n_clips), dim3(64 * XQ_GRP), lds, st, L, b->fir,
                        n_frames, out);
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
