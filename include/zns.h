@@ -151,6 +151,22 @@ int zns_xqt_f32(const float* wav, int n_clips, int n_samples, int sample_rate, i
 int zns_shift_gather_f32(const float* bank, int bank_T, const int32_t* clip, const int32_t* start,
                          int n_items, int T, float* out, void* stream);
 
+/* ------------------------------------------------------------------ online clip selection (pretext.py:30-86)
+ * zns_stem_mix_f32: anchor = stems[0] + stems[1] + ... in that order, float32 (pretext.py:50-61: every stem
+ * except "drums", in dict order).  stems: host array of n_stems (<= 8) device pointers, n samples each.
+ *
+ * zns_rms_gate_f32: processing/stem_check.py:22-51 (check_CL_clips) with compute_rms (:8-19) =
+ * librosa.feature.rms(frame_length=2048, hop_length=512, center=True, pad_mode="reflect").  Evaluates n_cand
+ * candidate crops of n_samples each in one launch: candidate c starts at anchor + start[c] / positive + start[c]
+ * (start: device int64[n_cand]; NULL = consecutive clips c * n_samples).  pass_count[c] (device int32) = number of
+ * frames with  rms_a > rms_p / 2  and  rms_a < rms_p * 4;  the caller divides by zns_rms_frames(n_samples) and
+ * applies lower_p < perc <= upper_p on the host, exactly as the reference does.  rms_a / rms_p: optional device
+ * outputs [n_cand][n_frames]. */
+int zns_stem_mix_f32(const float* const* stems, int n_stems, long long n, float* out, void* stream);
+int zns_rms_frames(int n_samples);
+int zns_rms_gate_f32(const float* anchor, const float* positive, const long long* start, int n_cand, int n_samples,
+                     float* rms_a, float* rms_p, int* pass_count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -149,3 +149,38 @@ def test_load_models_rules():
     opt.step()
     crit, opt, model = load_models("vanilla", "", 1e-4)
     assert type(model).__name__ == "DS_CNN" and opt.param_groups[0]["lr"] == 1e-4
+
+
+def test_clmr_trainer_matches_two_pass_module_path():
+    """pt_task "clmr" (pretext.py:494-511): ONE DS_CNN on both views.  The fused trainer runs it as a single stack
+    over the 2B rows; the reference structure is two autograd passes whose weight gradients add up."""
+    from zeronotesamba_amd.models.loss_functions import NTXent
+    from zeronotesamba_amd.models.models import DS_CNN, Pretext_CNN
+    from zeronotesamba_amd.pretext import PretextTrainer
+    B, T, tau = 4, 64, 0.25
+    sd = {k[len("anchor."):]: v for k, v in cnn_ref.synth_state_dict(9, 2.0).items() if k.startswith("anchor.")}
+    ma, mb = DS_CNN(), DS_CNN()
+    ma.load_state_dict(sd)
+    mb.load_state_dict(sd)
+    ma, mb = ma.to(DEV).eval(), mb.to(DEV)
+    batch = cnn_ref.synth_vqt(210, (B, 2, 96, T))
+    crit = NTXent(B, tau)
+    loss, cp, cn = crit(ma(batch[:, 0:1].to(DEV)), ma(batch[:, 1:2].to(DEV)))
+    loss.backward()
+    tr = PretextTrainer(mb, batch_len=B, temperature=tau, lr=1e-4, train=False)
+    assert tr.pt_task == "clmr" and tr.nbr == 1
+    out3 = tr.step(tr.stack_inputs(batch), update=False).tolist()
+    assert abs(out3[0] - loss.item()) < 2e-6 and abs(out3[1] - cp) < 2e-6 and abs(out3[2] - cn) < 2e-6
+    for (ka, va), (kb, vb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert ka == kb
+        ref = va.grad
+        err = (vb.grad - ref).norm().item() / max(ref.norm().item(), 1e-30)
+        assert err < 1e-2, (ka, err)     # split-K order differs between B and 2B rows; see DESIGN.md section 6
+    ev = tr.evaluate(tr.stack_inputs(batch)).tolist()
+    assert abs(ev[0] - loss.item()) < 2e-6
+    with pytest.raises(TypeError):
+        PretextTrainer(mb, pt_task="zerons")
+    with pytest.raises(ValueError):
+        PretextTrainer(mb, pt_task="byol")
+    with pytest.raises(TypeError):
+        PretextTrainer(Pretext_CNN().to(DEV), pt_task="clmr")

@@ -46,6 +46,9 @@ SIGNATURES = {
                                     C.POINTER(C.c_double)]),
     "zns_xqt_f32": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp, C.c_size_t, c_fp]),
     "zns_shift_gather_f32": (C.c_int, [c_fp, C.c_int, c_fp, c_fp, C.c_int, C.c_int, c_fp, c_fp]),
+    "zns_stem_mix_f32": (C.c_int, [c_fp, C.c_int, C.c_longlong, c_fp, c_fp]),
+    "zns_rms_frames": (C.c_int, [C.c_int]),
+    "zns_rms_gate_f32": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp]),
 }
 
 ZNS_IMPL_AUTO, ZNS_IMPL_NAIVE, ZNS_IMPL_DIRECT = 0, 1, 2

@@ -266,6 +266,56 @@ __global__ void shift_gather_kernel(const float* __restrict__ bank, int bank_T, 
     for (int t = threadIdx.x; t < T; t += blockDim.x) dst[t] = src[t];
 }
 
+
+// ------------------------------------------------------------------ RMS stem gate (processing/stem_check.py:8-51)
+constexpr int RMS_FRAME = 2048, RMS_HOP = 512;
+
+struct StemPtrs {
+    const float* p[8];
+};
+
+// anchor[:] = first non-drum stem; anchor[:] += every further one, in dict order (pretext.py:50-61): float32, that order
+__global__ void stem_mix_kernel(StemPtrs st, int n_stems, long long n, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float acc = st.p[0][i];
+    for (int k = 1; k < n_stems; ++k) acc += st.p[k][i];
+    out[i] = acc;
+}
+
+// one wave per (frame, candidate): librosa.feature.rms(frame_length=2048, hop_length=512, center=True, reflect pad)
+// of both signals, then the two ratio tests of check_CL_clips.  Squares are float32 like np.abs(x)**2; the 2048-term
+// sum is carried in float64 and rounded once (numpy's float32 running sum differs in the last bits only).
+__global__ void __launch_bounds__(64) rms_gate_kernel(const float* __restrict__ a, const float* __restrict__ p,
+                                                      const long long* __restrict__ start, int n_samples,
+                                                      int n_frames, float* __restrict__ rms_a,
+                                                      float* __restrict__ rms_p, int* __restrict__ pass_count) {
+    const int f = blockIdx.x, c = blockIdx.y;
+    const long long s0 = start ? start[c] : (long long)c * n_samples;
+    const float* xa = a + s0;
+    const float* xp = p + s0;
+    double sa = 0.0, sp = 0.0;
+    for (int j = threadIdx.x; j < RMS_FRAME; j += 64) {
+        int idx = f * RMS_HOP + j - RMS_FRAME / 2;
+        if (idx < 0) idx = -idx;
+        if (idx >= n_samples) idx = 2 * (n_samples - 1) - idx;
+        const float va = xa[idx], vp = xp[idx];
+        sa += (double)(va * va);
+        sp += (double)(vp * vp);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sa += __shfl_xor(sa, off, 64);
+        sp += __shfl_xor(sp, off, 64);
+    }
+    if (threadIdx.x == 0) {
+        const float ra = sqrtf((float)(sa / RMS_FRAME)), rp = sqrtf((float)(sp / RMS_FRAME));
+        if (rms_a) rms_a[(size_t)c * n_frames + f] = ra;
+        if (rms_p) rms_p[(size_t)c * n_frames + f] = rp;
+        if (ra > rp / 2.0f && ra < rp * 4.0f) atomicAdd(pass_count + c, 1);   // integer: order-independent
+    }
+}
+
 }  // namespace zns
 
 using namespace zns;
@@ -364,6 +414,33 @@ int zns_shift_gather_f32(const float* bank, int bank_T, const int32_t* clip, con
     ZNS_CHECK_ARG(n_items > 0 && T > 0 && bank_T >= T, "shift_gather: bad shape");
     hipLaunchKernelGGL(shift_gather_kernel, dim3(2 * n_items * 96), dim3(128), 0, (hipStream_t)stream, bank, bank_T,
                        clip, start, n_items, T, out);
+    ZNS_LAUNCH_CHECK();
+    return ZNS_OK;
+}
+
+int zns_stem_mix_f32(const float* const* stems, int n_stems, long long n, float* out, void* stream) {
+    ZNS_CHECK_ARG(n_stems >= 1 && n_stems <= 8 && n > 0, "stem_mix: need 1..8 stems and n > 0 (got %d, %lld)", n_stems, n);
+    StemPtrs st{};
+    for (int i = 0; i < n_stems; ++i) st.p[i] = stems[i];
+    hipLaunchKernelGGL(stem_mix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, st,
+                       n_stems, n, out);
+    ZNS_LAUNCH_CHECK();
+    return ZNS_OK;
+}
+
+int zns_rms_frames(int n_samples) { return n_samples < 0 ? 0 : 1 + n_samples / RMS_HOP; }
+
+int zns_rms_gate_f32(const float* anchor, const float* positive, const long long* start, int n_cand, int n_samples,
+                     float* rms_a, float* rms_p, int* pass_count, void* stream) {
+    ZNS_CHECK_ARG(n_cand >= 1 && n_samples > RMS_FRAME / 2,
+                  "rms_gate: need n_cand >= 1 and more than %d samples for the reflect padding (got %d, %d)",
+                  RMS_FRAME / 2, n_cand, n_samples);
+    ZNS_CHECK_ARG(pass_count != nullptr, "rms_gate: pass_count is required");
+    hipStream_t st = (hipStream_t)stream;
+    ZNS_HIP(hipMemsetAsync(pass_count, 0, sizeof(int) * n_cand, st));
+    const int n_frames = zns_rms_frames(n_samples);
+    hipLaunchKernelGGL(rms_gate_kernel, dim3(n_frames, n_cand), dim3(64), 0, st, anchor, positive, start, n_samples,
+                       n_frames, rms_a, rms_p, pass_count);
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
 }

@@ -15,7 +15,7 @@ Data parallelism (new: the reference has none): one proces
 whole 16-item batches (16 shifts of one clip, pretext.py:312-318) and computes its local NT-Xent;
 gradients are summed over ranks and scaled by 1/world_size inside the Adam kernel.
 """
-from typing import Any, Iterable, List, Optional, Sequence, Tuple
+from typing import Any, Dict, Iterable, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -150,9 +150,20 @@ class ShiftBank:
 class PretextTrainer:
     """Fused pretext step over flat parameter / gradient / moment buffers (see module docstring)."""
 
-    def __init__(self, model: Pretext_CNN, batch_len: int = 16, temperature: float = 0.25, lr: float = 1e-6,
+    def __init__(self, model: torch.nn.Module, batch_len: int = 16, temperature: float = 0.25, lr: float = 1e-6,
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, seed: int = 0,
-                 process_group: Any = None, train: bool = True):
+                 process_group: Any = None, train: bool = True, pt_task: Optional[str] = None):
+        """model: Pretext_CNN (pt_task "zerons", two independent branches) or DS_CNN (pt_task "clmr": ONE
+        network applied to both views, pretext.py:494-511 -- run here as a single stack over the 2B rows, so
+        its weight gradient is the sum over both views exactly as two autograd passes would give)."""
+        if pt_task is None:
+            pt_task = "zerons" if isinstance(model, Pretext_CNN) else "clmr"
+        if pt_task not in ("zerons", "clmr"):
+            raise ValueError("Which pretext task are we running?")
+        if (pt_task == "zerons") != isinstance(model, Pretext_CNN) or (pt_task == "clmr" and not isinstance(model, DS_CNN)):
+            raise TypeError(f"pt_task={pt_task!r} needs a {'Pretext_CNN' if pt_task == 'zerons' else 'DS_CNN'}, "
+                            f"got {type(model).__name__}")
+        self.pt_task = pt_task
         self.model = model
         self.batch_len, self.temperature = batch_len, temperature
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -172,13 +183,15 @@ class PretextTrainer:
         dev = next(m.parameters()).device
         _ops.require_device(next(m.parameters()), "model parameters")
         # backward order: fc1, cv8 .. cv1; inside a layer: anchor w, b, postve w, b
+        branches = (("anchor", m.anchor), ("postve", m.postve)) if self.pt_task == "zerons" else (("model", m),)
+        self.nbr = len(branches)
         order: List[Tuple[str, torch.nn.Parameter]] = []
         self.layer_slices = {}
         off = 0
         names = ["fc1"] + [n for n, *_ in reversed(_ops.LAYERS)]
         for lname in names:
             start = off
-            for brname, br in (("anchor", m.anchor), ("postve", m.postve)):
+            for brname, br in branches:
                 mod = br.fc1 if lname == "fc1" else getattr(br.pretrained, lname)
                 for pname in ("weight", "bias"):
                     p = getattr(mod, pname)
@@ -201,9 +214,9 @@ class PretextTrainer:
             p.grad = gv
             self._views.append((p, pv.data_ptr()))
             o += (n + 3) // 4 * 4
-        self.P = _ops.StackParams.from_flat(m.anchor.stack_params() + m.postve.stack_params(), 2)
-        grads = [p.grad for p in m.anchor.stack_params() + m.postve.stack_params()]
-        self.G = _ops.StackParams.from_flat(grads, 2)
+        plist = [p for _, br in branches for p in br.stack_params()]
+        self.P = _ops.StackParams.from_flat(plist, self.nbr)
+        self.G = _ops.StackParams.from_flat([p.grad for p in plist], self.nbr)
         # all-reduce buckets: consecutive layers (in backward order) until >= _BUCKET_MIN_FLOATS
         self.buckets = make_buckets([(n, *self.layer_slices[n]) for n in names], _BUCKET_MIN_FLOATS)
         self.reducer = GradBucketReducer(self.flat_g, self.buckets, self.pg) if self.world > 1 else None
@@ -235,7 +248,8 @@ class PretextTrainer:
         drop_p = _ops.DROP_P if self.train_mode else 0.0
         inv_keep = 1.0 / (1.0 - drop_p)
         seed = self._next_seed()
-        emb, acts, argm = _ops.stack_forward(x, self.P, B, drop_p, seed, save=True)
+        Bs = 2 * B // self.nbr     # rows per stack: B for the twin launch, 2B for the shared (clmr) network
+        emb, acts, argm = _ops.stack_forward(x, self.P, Bs, drop_p, seed, save=True)
         out3 = torch.empty(3, dtype=torch.float32, device=x.device)
         demb = torch.empty_like(emb)
         rc = _lib.lib().zns_ntxent_f32(emb.data_ptr(), emb[B:].data_ptr(), B, T, self.batch_len,
@@ -243,7 +257,7 @@ class PretextTrainer:
                                        demb[B:].data_ptr(), 1.0, _ops.stream_ptr())
         _lib.check(rc, "zns_ntxent_f32")
         hook = self.reducer.layer_done if self.reducer is not None else None
-        _ops.stack_backward(x, self.P, B, acts, argm, emb, demb, None, inv_keep, self.G, accumulate=False,
+        _ops.stack_backward(x, self.P, Bs, acts, argm, emb, demb, None, inv_keep, self.G, accumulate=False,
                             after_layer=hook)
         if self.reducer is not None:
             self.reducer.wait()
@@ -260,7 +274,7 @@ class PretextTrainer:
     def evaluate(self, x: torch.Tensor) -> torch.Tensor:
         B = x.shape[0] // 2
         T = x.shape[-1]
-        emb, _, _ = _ops.stack_forward(x, self.P, B, 0.0, 0, save=False)
+        emb, _, _ = _ops.stack_forward(x, self.P, 2 * B // self.nbr, 0.0, 0, save=False)
         out3 = torch.empty(3, dtype=torch.float32, device=x.device)
         rc = _lib.lib().zns_ntxent_f32(emb.data_ptr(), emb[B:].data_ptr(), B, T, self.batch_len,
                                        float(self.temperature), out3.data_ptr(), None, None, 1.0, _ops.stream_ptr())
@@ -279,3 +293,108 @@ class PretextTrainer:
             n += 1
         l, p, ng = (acc / max(n, 1)).tolist()
         return l, p, ng
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Online path: stems -> mix -> RMS-gated random crop -> VQT -> resident bank, all on
+# the device.  pretext.py:30-86 (drum_anchor_positive) and :143-170 (bank fill) without the pickle round trip.
+
+def mix_stems(stems: Dict[str, Any], device=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """pretext.py:46-64: positive = the "drums" stem, anchor = float32 sum of every other stem in dict order."""
+    from .processing.stem_check import to_device_signal
+    others = [to_device_signal(sig, f"stem {name!r}") for name, sig in stems.items() if name != "drums"]
+    if not others:
+        raise Exception("Anchor is still None.")
+    if "drums" not in stems:
+        raise KeyError("stems has no 'drums' entry")
+    pos = to_device_signal(stems["drums"], "stem 'drums'")
+    n = others[0].numel()
+    if any(o.numel() != n for o in others) or pos.numel() != n:
+        raise ValueError("all stems must have the same length")
+    anchor = torch.empty(n, dtype=torch.float32, device=pos.device)
+    rc = _lib.lib().zns_stem_mix_f32(_lib.ptr_array([o.data_ptr() for o in others]), len(others), n,
+                                     anchor.data_ptr(), _ops.stream_ptr())
+    _lib.check(rc, "zns_stem_mix_f32")
+    anchor._zns_keep = others      # sources must outlive the enqueued kernel
+    return anchor, pos
+
+
+def select_clip(anchor: torch.Tensor, positive: torch.Tensor, length: int, lower_p: float, upper_p: float,
+                rng=None, speculate: int = 8) -> int:
+    """The `while rms_bool == False` loop of pretext.py:66-84: draw `randint(0, stop)` until the crop passes the RMS
+    gate, halving lower_p after the 10th try.  `speculate` candidates are gated per launch; the generator is rewound
+    so it ends up having consumed exactly the draws the reference would have made."""
+    import random as _random
+    from .processing.stem_check import gate_counts
+    r = rng if rng is not None else _random
+    n = int(length) * 16000
+    stop = anchor.numel() - n - 1
+    if stop < 0:
+        raise ValueError(f"signal of {anchor.numel()} samples is shorter than a {length} s clip")
+    tries = 0
+    while True:
+        state = r.getstate()
+        cands = [r.randint(0, stop) for _ in range(speculate)]
+        counts, n_frames, _, _ = gate_counts(anchor, positive, cands, n)
+        for j, c in enumerate(counts.tolist()):
+            ok = lower_p < c / n_frames <= upper_p
+            tries += 1
+            if tries > 9:
+                lower_p = lower_p / 2
+            if ok:
+                r.setstate(state)
+                for _ in range(j + 1):
+                    r.randint(0, stop)
+                return cands[j]
+
+
+def _yml(ymldict) -> Tuple[int, str, float, float]:
+    return (int(float(ymldict.get("clip_len", -1))), str(ymldict.get("input_mode", "")),
+            float(ymldict.get("lower_p", -1.0)), float(ymldict.get("upper_p", -1.0)))
+
+
+def drum_anchor_positive(stems: Dict[str, Any], ymldict, rng=None):
+    """
+    Function for generating anchor and positive samples.
+    -- stems: dictionary of stem names and signals
+    -- ymldict: YAML dictionary
+    Same 4-tuple as pretext.py:30-86 (numpy arrays): full-length anchor mix, drums, and the two XQTs of the crop.
+    """
+    from .processing.input_rep import generate_XQT_batch
+    length, mode, lower_p, upper_p = _yml(ymldict)
+    anchor, pos = mix_stems(stems)
+    start = select_clip(anchor, pos, length, lower_p, upper_p, rng)
+    n = length * 16000
+    crops = torch.stack([anchor[start:start + n], pos[start:start + n]])
+    xqt = generate_XQT_batch(crops, 16000, mode)
+    return anchor.cpu().numpy(), pos.cpu().numpy(), xqt[0].cpu().numpy(), xqt[1].cpu().numpy()
+
+
+def fill_memory_bank(all_stems: Dict[str, Dict[str, Any]], fps: Sequence[str], ymldict, rng=None,
+                     chunk: int = 256) -> torch.Tensor:
+    """The bank-filling loop of create_memory_bank (pretext.py:143-170) for stems that are already loaded:
+    one (anchor, positive) XQT pair per file path, in `fps` order, written straight into a device-resident
+    `(len(fps), 2, 96, T)` bank (feed it to ShiftBank).  Audio decoding and the pickle dump are out of scope."""
+    from .processing.input_rep import generate_XQT_batch
+    length, mode, lower_p, upper_p = _yml(ymldict)
+    n = length * 16000
+    bank = None
+    staged: Optional[torch.Tensor] = None
+    done = 0
+    for i, fp in enumerate(fps):
+        anchor, pos = mix_stems(all_stems[fp.strip()])
+        start = select_clip(anchor, pos, length, lower_p, upper_p, rng)
+        if staged is None:
+            staged = torch.empty((min(chunk, len(fps)), 2, n), dtype=torch.float32, device=anchor.device)
+        j = i - done
+        staged[j, 0].copy_(anchor[start:start + n])
+        staged[j, 1].copy_(pos[start:start + n])
+        if j + 1 == staged.shape[0] or i + 1 == len(fps):
+            xqt = generate_XQT_batch(staged[:j + 1].reshape(2 * (j + 1), n), 16000, mode)
+            if bank is None:
+                bank = torch.empty((len(fps), 2, xqt.shape[1], xqt.shape[2]), dtype=torch.float32, device=xqt.device)
+            bank[done:i + 1] = xqt.reshape(j + 1, 2, xqt.shape[1], xqt.shape[2])
+            done = i + 1
+    if bank is None:
+        raise ValueError("fill_memory_bank: no file paths")
+    return bank
