@@ -184,3 +184,31 @@ def test_clmr_trainer_matches_two_pass_module_path():
         PretextTrainer(mb, pt_task="byol")
     with pytest.raises(TypeError):
         PretextTrainer(Pretext_CNN().to(DEV), pt_task="clmr")
+
+
+def test_rccl_bucketed_allreduce_on_the_launch_streams():
+    """The data-parallel step on a REAL RCCL group (one rank: this box has one GPU).  The bucketed async all-reduces
+    run on RCCL's stream between the backward kernels; with one rank they must leave the step bitwise unchanged,
+    which checks the stream ordering (reduce after the layer's gradient kernels, Adam after the reduce)."""
+    import socket
+    import torch.distributed as dist
+    from zeronotesamba_amd.distributed import GradBucketReducer
+    from zeronotesamba_amd.pretext import PretextTrainer
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        B, T = 4, 64
+        ta = PretextTrainer(make_model(3), batch_len=B, lr=1e-4, seed=3)
+        tb = PretextTrainer(make_model(3), batch_len=B, lr=1e-4, seed=3)
+        tb.reducer = GradBucketReducer(tb.flat_g, tb.buckets, None, always=True)
+        assert len(tb.buckets) >= 3 and tb.buckets[-1][2] == tb.n_flat
+        x = ta.stack_inputs(cnn_ref.synth_vqt(77, (B, 2, 96, T)))
+        for _ in range(3):
+            oa, ob = ta.step(x), tb.step(x)
+        assert torch.equal(oa, ob) and torch.equal(ta.flat_g, tb.flat_g) and torch.equal(ta.flat_p, tb.flat_p)
+    finally:
+        dist.destroy_process_group()

@@ -56,7 +56,10 @@ def make_buckets(layer_slices: Sequence[Tuple[str, int, int]], min_floats: int) 
 class GradBucketReducer:
     """Sums slices of one flat gradient buffer across ranks, asynchronously, bucket by bucket."""
 
-    def __init__(self, flat_grad: torch.Tensor, buckets: Sequence[Tuple[str, int, int]], group: Any = None):
+    def __init__(self, flat_grad: torch.Tensor, buckets: Sequence[Tuple[str, int, int]], group: Any = None,
+                 always: bool = False):
+        """always=True issues the collectives even in a one-rank group (smoke-testing RCCL on a single GPU)."""
+        self.always = always
         self.flat = flat_grad
         self.by_last = {name: (s, e) for name, s, e in buckets}
         self.group = group
@@ -72,7 +75,7 @@ class GradBucketReducer:
 
     def layer_done(self, name: str) -> None:
         """Call after layer `name`'s gradient kernels have been enqueued on the current stream."""
-        if self.world > 1 and name in self.by_last:
+        if (self.world > 1 or self.always) and name in self.by_last:
             s, e = self.by_last[name]
             self.handles.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group,
                                                 async_op=True))
