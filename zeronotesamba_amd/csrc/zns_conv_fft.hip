@@ -48,8 +48,12 @@ __device__ __forceinline__ void twiddle_init(float2* tw) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// x [nb, C, H, T] -> S [nb][FF][2C][P].  Window of block b starts at column b*V - off and has `valid` live
-// samples (64 for the overlapped correlation windows, V for the zero-padded blocks of backward-weights' dZ).
+// Windows are addressed by ONE flattened index per sample, q = (c * H + h) * NB + b = c * P + p: the spectrum planes
+// S[n][slot][C][P] and the activation rows x[n][C][H][T] are both contiguous in it, so a block takes 256 consecutive
+// q regardless of how small a single channel's P is (cv5/cv6: P = 96) and every lane of every wave has a window.
+//
+// x [nb, C, H, T] -> S [nb][FS][C][P].  Window b of a row starts at column b*V - off and has `valid` live samples
+// (64 for the overlapped correlation windows, V for the zero-padded blocks of backward-weights' dZ).
 __global__ void __launch_bounds__(256) spec_fwd_kernel(const float* __restrict__ x, float* __restrict__ S, int C,
                                                        int H, int T, int V, int NB, int off, int valid, int chunks,
                                                        float third_sign) {
@@ -57,30 +61,34 @@ __global__ void __launch_bounds__(256) spec_fwd_kernel(const float* __restrict__
     // (64 consecutive samples); all 64 fetches of a wave are issued before the first LDS write.  Each lane then
     // reads back its own window (row stride 65 floats: conflict free) and transforms it in registers.
     __shared__ float win[256 * (FN + 1)];
-    const int P = H * NB;
+    const int CP = C * H * NB;
     const int chunk = blockIdx.x % chunks;
-    const int plane = blockIdx.x / chunks;          // n * C + c
-    const int c = plane % C, n = plane / C;
+    const int n = blockIdx.x / chunks;
     const int lane = threadIdx.x & 63;
-    const int wbase = (threadIdx.x >> 6) * 64;
-    const float* xp = x + (size_t)plane * H * T;
+    const int wbase = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * 64);
+    const float* xn = x + (size_t)n * C * H * T;
     float xw[FN];
+    {
+        // wave-uniform walk: (row R = c*H + h, window bb) of the 64 windows this wave fetches
+        const int qw = chunk * 256 + wbase;
+        int R = qw / NB, bb = qw - R * NB;
+        int left = CP - qw;                           // windows that exist from here on
 #pragma unroll
-    for (int i = 0; i < FN; ++i) {
-        const int pw = chunk * 256 + wbase + i;       // wave-uniform window index
-        const int hh = pw / NB, bb = pw - hh * NB;
-        const int col = bb * V - off + lane;
-        xw[i] = (pw < P && lane < valid && col >= 0 && col < T) ? xp[(size_t)hh * T + col] : 0.f;
+        for (int i = 0; i < FN; ++i) {
+            const int col = bb * V - off + lane;
+            xw[i] = (i < left && lane < valid && col >= 0 && col < T) ? xn[(size_t)R * T + col] : 0.f;
+            if (++bb == NB) { bb = 0; ++R; }
+        }
     }
 #pragma unroll
     for (int i = 0; i < FN; ++i) win[(wbase + i) * (FN + 1) + lane] = xw[i];
     __syncthreads();
-    const int p = chunk * 256 + threadIdx.x;
-    if (p >= P) return;
+    const int q = chunk * 256 + threadIdx.x;
+    if (q >= CP) return;
 #pragma unroll
     for (int m = 0; m < FN; ++m) xw[m] = win[threadIdx.x * (FN + 1) + m];
-    float* out = S + (((size_t)n * FS) * C + c) * P + p;
-    const size_t tstride = (size_t)C * P;       // between the three planes of one frequency
+    float* out = S + (size_t)n * FS * CP + q;
+    const size_t tstride = (size_t)CP;          // between consecutive slots
     float sr[FF], si[FF];
     rfft64(xw, sr, si);
 #pragma unroll
@@ -91,10 +99,14 @@ __global__ void __launch_bounds__(256) spec_fwd_kernel(const float* __restrict__
     }
 }
 
-// S [nb][FF][2C][P] -> inverse 64-point real FFT of each window, first V samples kept, with the layer epilogue fused:
+// S [nb][FS][C][P] -> inverse 64-point real FFT of each window, first V samples kept, with the layer epilogue fused:
 //   MODE 0  z  = raw conv output                                         (plain store)
-//   MODE 1  y  = dropout(relu(maxpool_rows(z) + bias)), arg-max rows     (forward: thread owns `pool` rows of a window)
+//   MODE 1  y  = dropout(relu(maxpool_rows(z) + bias)), arg-max rows     (forward)
 //   MODE 2  dx = max-unpool(mask(z))                                      (backward-data epilogue, see zns.h)
+// A block owns WPB consecutive windows of the flattened index, WPB a multiple of pool*NB so that the `pool` rows of
+// every pooling group are inside the block.  Phase 1: every thread inverts ONE window into the LDS tile.  Phase 2:
+// the block's outputs form (almost) one contiguous run of the result; they are written coalesced, and the row
+// pooling (max + arg-max over the group's `pool` windows) happens on the way out of LDS.
 struct InvEpi {
     Ptr2 bias;                 // MODE 1
     uint8_t* argmax;
@@ -105,97 +117,86 @@ struct InvEpi {
     const float* xmask;        // MODE 2
     const uint8_t* prev_argmax;
     int prev_pool;
+    uint32_t mV, mNB, mHq;     // ceil(2^32 / d) for the epilogue's index divisions (exact for x * d < 2^32)
 };
 
 constexpr int IVMAX = FN - 12;     // V <= 52 (kw >= 13)
-constexpr int IVS = IVMAX + 1;     // odd LDS stride: the per-lane rows of the staging tile hit distinct banks
+
+__device__ __forceinline__ int fastdiv(int x, int d, uint32_t magic) { return d == 1 ? x : (int)__umulhi((uint32_t)x, magic); }
+static uint32_t div_magic(int d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); }
 
 template <int MODE>
 __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__ S, float* __restrict__ out, int C, int H,
-                                                       int T, int V, int NB, int chunks, InvEpi E) {
-    __shared__ float stage[256 * IVS];
-    __shared__ uint8_t stage_am[MODE == 1 ? 256 * IVMAX : 4];
+                                                       int T, int V, int NB, int chunks, int WPB, InvEpi E) {
+    extern __shared__ __attribute__((aligned(16))) float stage[];   // [256][VS], VS odd: per-lane rows hit distinct banks
     const int pool = MODE == 1 ? E.pool : 1;
-    const int Hq = H / pool;                       // output rows per plane (pooled rows in MODE 1)
-    const int Pq = Hq * NB;
+    const int Hq = H / pool;                       // output rows per channel (pooled rows in MODE 1)
+    const int CP = C * H * NB;
+    const int VS = V | 1;
     const int chunk = blockIdx.x % chunks;
-    const int plane = blockIdx.x / chunks;
-    const int c = plane % C, n = plane / C;
-    const int pq = chunk * 256 + threadIdx.x;
-    const bool active = pq < Pq;
-    const int P = H * NB;
-    const unsigned tstride = (unsigned)C * P * 4u;       // bytes between consecutive slots
-    float* sbase = const_cast<float*>(S) + (((size_t)n * FS) * C + c) * P;
-    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(sbase, 0, (int)(tstride * (FS - 1) + P * 4u), 0x00020000);
-    if (active) {
-        const int hq = pq / NB, b = pq - hq * NB;
-        float* mine = stage + threadIdx.x * IVS;          // running maximum lives in LDS, not in 52 more registers
-#pragma unroll 1
-        for (int a = 0; a < pool; ++a) {
-            const int h = hq * pool + a;
-            const unsigned voff = (unsigned)(h * NB + b) * 4u;
-            float yr[FF], yi[FF];
-            yr[0] = spec_load(rs, voff, 0);                  // DC
-            yi[0] = spec_load(rs, voff, tstride);            // Nyquist
+    const int n = blockIdx.x / chunks;
+    const int q0 = chunk * WPB;
+    const int nwin = min(WPB, CP - q0);            // a multiple of pool * NB
+    const unsigned tstride = (unsigned)CP * 4u;    // bytes between consecutive slots
+    float* sbase = const_cast<float*>(S) + (size_t)n * FS * CP;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(sbase, 0, (int)(tstride * FS), 0x00020000);
+    if ((int)threadIdx.x < nwin) {
+        const unsigned voff = (unsigned)(q0 + threadIdx.x) * 4u;
+        float yr[FF], yi[FF];
+        yr[0] = spec_load(rs, voff, 0);                  // DC
+        yi[0] = spec_load(rs, voff, tstride);            // Nyquist
 #pragma unroll
-            for (int f = 1; f < FF; ++f) {
-                const float q1 = spec_load(rs, voff, (3 * f) * tstride), q2 = spec_load(rs, voff, (3 * f + 1) * tstride),
-                            q3 = spec_load(rs, voff, (3 * f + 2) * tstride);
-                yr[f] = q1 - q2;
-                yi[f] = q3 - q1 - q2;
-            }
-            float xo[FN];
-            irfft64(yr, yi, xo);
-            if (a == 0) {
-#pragma unroll
-                for (int v = 0; v < IVMAX; ++v) {
-                    mine[v] = xo[v];
-                    if (MODE == 1) stage_am[threadIdx.x * IVMAX + v] = 0;
-                }
-            } else {
-#pragma unroll
-                for (int v = 0; v < IVMAX; ++v) {
-                    if (xo[v] > mine[v]) {             // first maximum wins, as ATen's max_pool2d
-                        mine[v] = xo[v];
-                        stage_am[threadIdx.x * IVMAX + v] = (uint8_t)a;
-                    }
-                }
-            }
+        for (int f = 1; f < FF; ++f) {
+            const float q1 = spec_load(rs, voff, (3 * f) * tstride), q2 = spec_load(rs, voff, (3 * f + 1) * tstride),
+                        q3 = spec_load(rs, voff, (3 * f + 2) * tstride);
+            yr[f] = q1 - q2;
+            yi[f] = q3 - q1 - q2;
         }
+        float xo[FN];
+        irfft64(yr, yi, xo);
+        float* mine = stage + threadIdx.x * VS;
+#pragma unroll
+        for (int v = 0; v < IVMAX; ++v)
+            if (v < V) mine[v] = xo[v];
     }
     __syncthreads();
-    // coalesced epilogue: the block's 256 windows are consecutive in (row, window) order, i.e. (almost) one contiguous
-    // run of the output; element e of the block = window e / V, sample e % V.
-    const int p0 = chunk * 256;
-    const int nwin = min(256, Pq - p0);
+    const int group = pool * NB;
+    const int Rq0 = q0 / group;                    // first (pooled) output row of this block, counted over (c, hq)
+    const int nout = (nwin / pool) * V;
     const int br = n / (MODE == 1 ? E.B : 1), bb = n - br * (MODE == 1 ? E.B : 1);
-    const float bv = MODE == 1 ? E.bias.p[br][c] : 0.f;
     const uint32_t lseed = MODE == 1 ? layer_seed(E.seed, E.layer, br) : 0u;
-    for (int e = threadIdx.x; e < nwin * V; e += 256) {
-        const int w = e / V, v = e - w * V;
-        const int p = p0 + w;
-        const int hq = p / NB, b = p - hq * NB;
+    for (int e = threadIdx.x; e < nout; e += 256) {
+        const int w = fastdiv(e, V, E.mV), v = e - w * V;          // pooled window inside the block, sample
+        const int lg = fastdiv(w, NB, E.mNB), b = w - lg * NB;     // pooling group inside the block, window in its row
         const int col = b * V + v;
         if (col >= T) continue;
-        float r = stage[w * IVS + v];
-        const size_t o = ((size_t)plane * Hq + hq) * T + col;
+        const int Rq = Rq0 + lg;                                   // = c * Hq + hq
+        const float* sp = stage + (lg * group + b) * VS + v;
+        float r = sp[0];
+        int am = 0;
+        for (int a = 1; a < pool; ++a) {
+            const float t = sp[a * NB * VS];
+            if (t > r) { r = t; am = a; }                           // first maximum wins, as ATen's max_pool2d
+        }
+        const size_t o = ((size_t)n * C * Hq + Rq) * T + col;
         if (MODE == 0) {
             out[o] = r;
         } else if (MODE == 1) {
-            r += bv;
+            const int c = fastdiv(Rq, Hq, E.mHq);
+            r += E.bias.p[br][c];
             r = r > 0.f ? r : 0.f;
             if (E.thresh) {
-                const uint64_t idx = (((uint64_t)bb * C + c) * Hq + hq) * T + col;
+                const uint64_t idx = ((uint64_t)bb * C * Hq + Rq) * T + col;
                 r = drop_keep(lseed, idx, E.thresh) ? r * E.inv_keep : 0.f;
             }
             out[o] = r;
-            if (E.argmax && pool > 1) E.argmax[o] = stage_am[w * IVMAX + v];
+            if (E.argmax && pool > 1) E.argmax[o] = (uint8_t)am;
         } else {
             if (E.xmask) r = (E.xmask[o] != 0.f) ? r * E.inv_keep : 0.f;
             const int pp = E.prev_pool;
             if (pp > 1) {
                 const int amx = E.prev_argmax[o];
-                float* d = out + (((size_t)plane * Hq + hq) * pp) * T + col;
+                float* d = out + (((size_t)n * C * Hq + Rq) * pp) * T + col;
                 for (int q = 0; q < pp; ++q) d[(size_t)q * T] = (q == amx) ? r : 0.f;
             } else {
                 out[o] = r;
@@ -438,20 +439,26 @@ size_t fft_spectrum_bytes(const ConvArgs& a) {
 
 static int run_spec_fwd(const float* x, float* S, int nb, int C, int H, int T, const FftGeom& g, int off, int valid,
                         float third_sign, hipStream_t st) {
-    const int chunks = ceil_div(g.P, 256);
-    hipLaunchKernelGGL(spec_fwd_kernel, dim3((unsigned)((size_t)nb * C * chunks)), dim3(256), 0, st, x, S, C, H, T, g.V,
+    const int chunks = ceil_div(C * g.P, 256);
+    hipLaunchKernelGGL(spec_fwd_kernel, dim3((unsigned)((size_t)nb * chunks)), dim3(256), 0, st, x, S, C, H, T, g.V,
                        g.NB, off, valid, chunks, third_sign);
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
 }
 
 template <int MODE>
-static int run_spec_inv(const float* S, float* out, int nb, int C, int H, int T, const FftGeom& g, const InvEpi& E,
+static int run_spec_inv(const float* S, float* out, int nb, int C, int H, int T, const FftGeom& g, InvEpi E,
                         hipStream_t st) {
     const int pool = MODE == 1 ? E.pool : 1;
-    const int chunks = ceil_div((H / pool) * g.NB, 256);
-    hipLaunchKernelGGL(spec_inv_kernel<MODE>, dim3((unsigned)((size_t)nb * C * chunks)), dim3(256), 0, st, S, out, C, H, T,
-                       g.V, g.NB, chunks, E);
+    const int group = pool * g.NB;
+    const int WPB = (256 / group) * group;
+    const int chunks = ceil_div(C * g.P, WPB);
+    E.mV = div_magic(g.V);
+    E.mNB = div_magic(g.NB);
+    E.mHq = div_magic(H / pool);
+    const size_t lds = (size_t)256 * (g.V | 1) * sizeof(float);
+    hipLaunchKernelGGL(spec_inv_kernel<MODE>, dim3((unsigned)((size_t)nb * chunks)), dim3(256), lds, st, S, out, C, H, T,
+                       g.V, g.NB, chunks, WPB, E);
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
 }
