@@ -165,41 +165,64 @@ __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__
     const int nout = (nwin / pool) * V;
     const int br = n / (MODE == 1 ? E.B : 1), bb = n - br * (MODE == 1 ? E.B : 1);
     const uint32_t lseed = MODE == 1 ? layer_seed(E.seed, E.layer, br) : 0u;
-    for (int e = threadIdx.x; e < nout; e += 256) {
-        const int w = fastdiv(e, V, E.mV), v = e - w * V;          // pooled window inside the block, sample
-        const int lg = fastdiv(w, NB, E.mNB), b = w - lg * NB;     // pooling group inside the block, window in its row
-        const int col = b * V + v;
-        if (col >= T) continue;
-        const int Rq = Rq0 + lg;                                   // = c * Hq + hq
-        const float* sp = stage + (lg * group + b) * VS + v;
-        float r = sp[0];
-        int am = 0;
-        for (int a = 1; a < pool; ++a) {
-            const float t = sp[a * NB * VS];
-            if (t > r) { r = t; am = a; }                           // first maximum wins, as ATen's max_pool2d
-        }
-        const size_t o = ((size_t)n * C * Hq + Rq) * T + col;
-        if (MODE == 0) {
-            out[o] = r;
-        } else if (MODE == 1) {
-            const int c = fastdiv(Rq, Hq, E.mHq);
-            r += E.bias.p[br][c];
-            r = r > 0.f ? r : 0.f;
-            if (E.thresh) {
-                const uint64_t idx = ((uint64_t)bb * C * Hq + Rq) * T + col;
-                r = drop_keep(lseed, idx, E.thresh) ? r * E.inv_keep : 0.f;
+    // four outputs per thread and trip: their global loads (mask, arg-max, bias) are all in flight before the first
+    // store, instead of one exposed memory round trip per element
+    constexpr int EU = 4;
+    for (int e0 = threadIdx.x; e0 < nout; e0 += 256 * EU) {
+        float r[EU], mk[EU];
+        size_t o[EU];
+        int am[EU], Rq[EU], col[EU];
+        bool ok[EU];
+#pragma unroll
+        for (int u = 0; u < EU; ++u) {
+            const int e = e0 + u * 256;
+            const int w = fastdiv(e, V, E.mV), v = e - w * V;          // pooled window inside the block, sample
+            const int lg = fastdiv(w, NB, E.mNB), b = w - lg * NB;     // pooling group inside the block, window in its row
+            col[u] = b * V + v;
+            ok[u] = e < nout && col[u] < T;
+            Rq[u] = Rq0 + lg;                                          // = c * Hq + hq
+            o[u] = ((size_t)n * C * Hq + Rq[u]) * T + col[u];
+            r[u] = 0.f;
+            am[u] = 0;
+            mk[u] = 1.f;
+            if (ok[u]) {
+                const float* sp = stage + (lg * group + b) * VS + v;
+                r[u] = sp[0];
+                for (int a = 1; a < pool; ++a) {
+                    const float t = sp[a * NB * VS];
+                    if (t > r[u]) { r[u] = t; am[u] = a; }             // first maximum wins, as ATen's max_pool2d
+                }
+                if (MODE == 1) mk[u] = E.bias.p[br][fastdiv(Rq[u], Hq, E.mHq)];
+                if (MODE == 2) {
+                    if (E.xmask) mk[u] = E.xmask[o[u]];
+                    if (E.prev_pool > 1) am[u] = E.prev_argmax[o[u]];
+                }
             }
-            out[o] = r;
-            if (E.argmax && pool > 1) E.argmax[o] = (uint8_t)am;
-        } else {
-            if (E.xmask) r = (E.xmask[o] != 0.f) ? r * E.inv_keep : 0.f;
-            const int pp = E.prev_pool;
-            if (pp > 1) {
-                const int amx = E.prev_argmax[o];
-                float* d = out + (((size_t)n * C * Hq + Rq) * pp) * T + col;
-                for (int q = 0; q < pp; ++q) d[(size_t)q * T] = (q == amx) ? r : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < EU; ++u) {
+            if (!ok[u]) continue;
+            float rr = r[u];
+            if (MODE == 0) {
+                out[o[u]] = rr;
+            } else if (MODE == 1) {
+                rr += mk[u];
+                rr = rr > 0.f ? rr : 0.f;
+                if (E.thresh) {
+                    const uint64_t idx = ((uint64_t)bb * C * Hq + Rq[u]) * T + col[u];
+                    rr = drop_keep(lseed, idx, E.thresh) ? rr * E.inv_keep : 0.f;
+                }
+                out[o[u]] = rr;
+                if (E.argmax && pool > 1) E.argmax[o[u]] = (uint8_t)am[u];
             } else {
-                out[o] = r;
+                if (E.xmask) rr = (mk[u] != 0.f) ? rr * E.inv_keep : 0.f;
+                const int pp = E.prev_pool;
+                if (pp > 1) {
+                    float* d = out + (((size_t)n * C * Hq + Rq[u]) * pp) * T + col[u];
+                    for (int q = 0; q < pp; ++q) d[(size_t)q * T] = (q == am[u]) ? rr : 0.f;
+                } else {
+                    out[o[u]] = rr;
+                }
             }
         }
     }
