@@ -64,77 +64,103 @@ __global__ void __launch_bounds__(256) cv1_fwd_kernel(int B, int T, int H, const
     }
 }
 
-// block -> (n, co, h); 128 threads, each owning 4 consecutive time steps per pass (one float4 of dZ, a 3 x 14 input
-// window in registers: 10.5 input loads per dZ element instead of 33).  Partial sums [33 taps + bias] per block into ws.
-__global__ void __launch_bounds__(128) cv1_wgrad_kernel(int T, int H, const float* __restrict__ dz,
+// Weight gradient: dW[co][r][s] = sum_{n,h,t} dZ[n,co,h,t] * x[n,h+r-1,t+s-5],  db[co] = sum dZ.
+// block -> (n, h); 4 waves: wave r < 3 owns kernel row r, lane = output channel, 11 tap accumulators per lane;
+// wave 3 accumulates the bias gradient.  Per 128-step time chunk the 64 x 128 dZ tile (row stride 129: conflict-free
+// per-channel reads) and the three zero-padded input rows are staged in LDS with coalesced loads; the input window
+// of a step is wave-uniform, i.e. LDS broadcast reads.  No cross-lane reduction at all: the block writes its
+// 34 x 64 partial sums tap-major (coalesced), cv1_wgrad_reduce adds the B*H blocks in a fixed order.
+constexpr int CW_TC = 128, CW_XS = CW_TC + 16, CW_K1 = CV1_KH * CV1_KW + 1;
+
+__global__ void __launch_bounds__(256) cv1_wgrad_kernel(int T, int H, const float* __restrict__ dz,
                                                         const float* __restrict__ x, float* __restrict__ part) {
-    __shared__ float red[2][CV1_KH * CV1_KW + 1];
-    const int h = blockIdx.x % H;
-    const int co = (blockIdx.x / H) % CV1_CO;
-    const int n = blockIdx.x / (H * CV1_CO);
-    const float* zp = dz + (((size_t)n * CV1_CO + co) * H + h) * T;
-    float acc[CV1_KH * CV1_KW + 1];
+    __shared__ float sdz[CV1_CO * (CW_TC + 1)];
+    __shared__ __attribute__((aligned(16))) float sx[CV1_KH * CW_XS];
+    const int h = blockIdx.x % H, n = blockIdx.x / H;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float acc[CV1_KW];
 #pragma unroll
-    for (int k = 0; k < CV1_KH * CV1_KW + 1; ++k) acc[k] = 0.f;
-    const bool vec = (T % 4 == 0);
-    for (int t0 = threadIdx.x * 4; t0 < T; t0 += 128 * 4) {
-        float g[4];
-        if (vec) {
-            const float4 v = *reinterpret_cast<const float4*>(zp + t0);
-            g[0] = v.x; g[1] = v.y; g[2] = v.z; g[3] = v.w;
-        } else {
+    for (int s = 0; s < CV1_KW; ++s) acc[s] = 0.f;
+    float bsum = 0.f;
+    for (int t0 = 0; t0 < T; t0 += CW_TC) {
+        __syncthreads();
+        // dZ tile: 8 loads in flight per thread, 512 contiguous bytes per channel row
 #pragma unroll
-            for (int k = 0; k < 4; ++k) g[k] = (t0 + k < T) ? zp[t0 + k] : 0.f;
-        }
-        acc[CV1_KH * CV1_KW] += (g[0] + g[1]) + (g[2] + g[3]);
+        for (int u = 0; u < CV1_CO * CW_TC / 256; u += 8) {
+            float v[8];
 #pragma unroll
-        for (int r = 0; r < CV1_KH; ++r) {
-            const int hh = h + r - 1;
-            const bool rok = hh >= 0 && hh < H;
-            const float* xp = x + ((size_t)n * H + (rok ? hh : 0)) * T;
-            float xw[4 + CV1_KW - 1];
-#pragma unroll
-            for (int c = 0; c < 4 + CV1_KW - 1; ++c) {
-                const int tt = t0 + c - 5;
-                xw[c] = (rok && tt >= 0 && tt < T) ? xp[tt] : 0.f;
+            for (int j = 0; j < 8; ++j) {
+                const int i = threadIdx.x + (u + j) * 256;
+                const int co = i / CW_TC, tt = i % CW_TC;
+                v[j] = (t0 + tt < T) ? dz[(((size_t)n * CV1_CO + co) * H + h) * T + t0 + tt] : 0.f;
             }
 #pragma unroll
-            for (int s = 0; s < CV1_KW; ++s)
+            for (int j = 0; j < 8; ++j) {
+                const int i = threadIdx.x + (u + j) * 256;
+                sdz[(i / CW_TC) * (CW_TC + 1) + (i % CW_TC)] = v[j];
+            }
+        }
+        for (int i = threadIdx.x; i < CV1_KH * CW_XS; i += 256) {
+            const int r = i / CW_XS, j = i % CW_XS;
+            const int hh = h + r - 1, tt = t0 + j - 5;
+            sx[i] = (hh >= 0 && hh < H && tt >= 0 && tt < T) ? x[((size_t)n * H + hh) * T + tt] : 0.f;
+        }
+        __syncthreads();
+        const float* zr = sdz + lane * (CW_TC + 1);
+        if (wv < CV1_KH) {
+            const float4* xr = reinterpret_cast<const float4*>(sx + wv * CW_XS);
+#pragma unroll 2
+            for (int tt = 0; tt < CW_TC; tt += 4) {
+                float xw[16];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) acc[r * CV1_KW + s] = fmaf(g[k], xw[k + s], acc[r * CV1_KW + s]);
+                for (int q = 0; q < 4; ++q) {
+                    const float4 f = xr[tt / 4 + q];            // x[t0 + tt + 4q - 5 ...], same address in every lane
+                    xw[4 * q] = f.x; xw[4 * q + 1] = f.y; xw[4 * q + 2] = f.z; xw[4 * q + 3] = f.w;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float z = zr[tt + k];
+#pragma unroll
+                    for (int s = 0; s < CV1_KW; ++s) acc[s] = fmaf(z, xw[k + s], acc[s]);
+                }
+            }
+        } else {
+#pragma unroll 8
+            for (int tt = 0; tt < CW_TC; ++tt) bsum += zr[tt];
         }
     }
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float* pb = part + (size_t)blockIdx.x * (CW_K1 * CV1_CO);
+    if (wv < CV1_KH) {
 #pragma unroll
-    for (int k = 0; k < CV1_KH * CV1_KW + 1; ++k) {
-        float v = acc[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (lane == 0) red[wid][k] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < CV1_KH * CV1_KW + 1) {
-        const int k = threadIdx.x;
-        part[(size_t)blockIdx.x * (CV1_KH * CV1_KW + 1) + k] = red[0][k] + red[1][k];
+        for (int s = 0; s < CV1_KW; ++s) pb[(wv * CV1_KW + s) * CV1_CO + lane] = acc[s];
+    } else {
+        pb[(CW_K1 - 1) * CV1_CO + lane] = bsum;
     }
 }
 
-// wave -> (br, co, k): sums the B*H partials of that tap in a fixed lane/tree order (deterministic)
-__global__ void __launch_bounds__(64) cv1_wgrad_reduce(int B, int H, const float* __restrict__ part, MPtr2 dw, MPtr2 db,
-                                                       int accumulate, int nbr) {
-    constexpr int K1 = CV1_KH * CV1_KW + 1;
-    const int o = blockIdx.x;
-    const int k = o % K1, co = (o / K1) % CV1_CO, br = o / (K1 * CV1_CO);
+// part [nbr*B*H][34][64] -> dW, db.  Block: 64 consecutive columns x 16 row phases; every column is summed in a fixed
+// order (phase-strided rows, then the 16 phases), so the result does not depend on scheduling.
+__global__ void __launch_bounds__(1024) cv1_wgrad_reduce(int B, int H, const float* __restrict__ part, MPtr2 dw, MPtr2 db,
+                                                         int accumulate, int nbr) {
+    __shared__ float red[16][64];
+    constexpr int NC = CW_K1 * CV1_CO;
+    const int br = blockIdx.x / (NC / 64);
+    const int j = (blockIdx.x % (NC / 64)) * 64 + (threadIdx.x & 63);
+    const int ph = threadIdx.x >> 6;
+    const float* p = part + (size_t)br * B * H * NC + j;
     float s = 0.f;
-    for (int i = threadIdx.x; i < B * H; i += 64) {
-        const int b = i / H, h = i - b * H;
-        s += part[((size_t)((br * B + b) * CV1_CO + co) * H + h) * K1 + k];
-    }
+#pragma unroll 8
+    for (int i = ph; i < B * H; i += 16) s += p[(size_t)i * NC];
+    red[ph][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (ph == 0) {
+        float tot = 0.f;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (threadIdx.x == 0) {
-        float* d = (k < K1 - 1) ? dw.p[br] + co * (K1 - 1) + k : db.p[br] + co;
-        *d = accumulate ? *d + s : s;
+        for (int q = 0; q < 16; ++q) tot += red[q][threadIdx.x];
+        const int k = j / CV1_CO, co = j % CV1_CO;
+        float* d = (k < CW_K1 - 1) ? dw.p[br] + co * (CW_K1 - 1) + k : db.p[br] + co;
+        *d = accumulate ? *d + tot : tot;
     }
 }
 
@@ -161,11 +187,10 @@ int cv1_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, MPtr
         return ZNS_ERR_WORKSPACE;
     }
     float* part = (float*)ws;
-    hipLaunchKernelGGL(cv1_wgrad_kernel, dim3(a.nbr * a.B * CV1_CO * a.H), dim3(128), 0, st, a.T, a.H, dz, x, part);
+    hipLaunchKernelGGL(cv1_wgrad_kernel, dim3(a.nbr * a.B * a.H), dim3(256), 0, st, a.T, a.H, dz, x, part);
     ZNS_LAUNCH_CHECK();
-    const int n = a.nbr * CV1_CO * (CV1_KH * CV1_KW + 1);
-    hipLaunchKernelGGL(cv1_wgrad_reduce, dim3(n), dim3(64), 0, st, a.B, a.H, part, dw, db, accumulate,
-                       a.nbr);
+    hipLaunchKernelGGL(cv1_wgrad_reduce, dim3(a.nbr * (CW_K1 * CV1_CO / 64)), dim3(1024), 0, st, a.B, a.H, part, dw, db,
+                       accumulate, a.nbr);
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
 }
