@@ -340,7 +340,7 @@ static __global__ void pack_weights_kernel(Ptr2 w, float* __restrict__ dst, int 
 //                                        backward-weights core
 // =====================================================================================================
 template <int CIN_, int COUT_, int KH_, int KW_, int H_, int MT_, int NS_, int WMW_, int WQ_, int R_, int DILMAX_ = 0,
-          int WCI_ = 1>
+          int WCI_ = 1, int CW_ = 64>
 struct WgCfg {
     static constexpr int WCI = WCI_;         // 32-channel input tiles per workgroup (one per wave group)
     static constexpr int CIN = CIN_, COUT = COUT_, KH = KH_, KW = KW_, H = H_;
@@ -350,16 +350,20 @@ struct WgCfg {
     static constexpr int COB = WMW * MT * 32;
     static constexpr int CIB = 32 * WCI;
     static constexpr int G = WQ * NS, Q = KH * KW, NQG = (Q + G - 1) / G;
-    static constexpr int CW = 64;                            // pixels per K-tile: one image row segment
+    static constexpr int CW = CW_;                           // pixels per K-tile: one image row segment (32 or 64)
+    static constexpr int LPR = CW / 4;                       // 16-byte chunks (= DMA lanes) per dZ row
+    static constexpr int RPI = 64 / LPR;                     // dZ rows staged by one 16-byte DMA instruction
+    static constexpr int ZKD = 64 / CW;                      // swizzle key = (co / ZKD) & (LPR - 1): conflict-free b128 reads
     static constexpr int PH = KH / 2, PW = KW / 2;
     static constexpr int RSPAN = KH == 1 ? 1 : (KW - 1 + G - 1) / KW + 1;  // kernel rows a workgroup's shifts touch
     static constexpr int PRW = RSPAN, PCW = CW + (KW - 1) * (DILMAX ? DILMAX : 1);
     static constexpr int PS = (PRW * PCW) | 1;               // odd plane stride: lanes (= channels) hit distinct banks
-    static constexpr int ZBUF = COB * CW;                    // dZ tile [COB][64], 16-byte chunks XOR-swizzled by co&15
+    static constexpr int ZBUF = COB * CW;                    // dZ tile [COB][CW], 16-byte chunks XOR-swizzled by the key above
     static constexpr int XBUF = ((CIB * PS + 63) / 64) * 64;
     static constexpr int NXI = (XBUF / 64 + NW - 1) / NW;    // X-patch DMA instructions per wave
     static constexpr int LDS_BYTES = 2 * (ZBUF + XBUF) * 4;
     static_assert(R == 1, "one image row per K-tile");
+    static_assert(CW == 32 || CW == 64, "K-tile width");
     static_assert(CIN % CIB == 0 && COUT % COB == 0, "tiling");
     static_assert(COB % 4 == 0 && MT * NS * 16 <= 160, "accumulator budget");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
@@ -392,17 +396,18 @@ __device__ __forceinline__ void wg_load_tile(const WgArgs& A, int br, int cob, i
     const size_t zplane = (size_t)C::H * T;
     const bool fastz = ((T & 3) == 0) && (w0 + C::CW <= T) && ((reinterpret_cast<uintptr_t>(A.dz) & 15) == 0);
     if (fastz) {
-        // 16 lanes x 16 B = one row segment; one DMA instruction stages 4 channels (1 KiB, LDS-linear)
-        for (int q = wid; q < C::COB / 4; q += C::NW) {
-            const int co = 4 * q + (lane >> 4);
-            const int c = (lane & 15) ^ (co & 15);
+        // LPR lanes x 16 B = one row segment; one DMA instruction stages RPI channels (1 KiB, LDS-linear)
+        for (int q = wid; q < C::COB / C::RPI; q += C::NW) {
+            const int co = C::RPI * q + lane / C::LPR;
+            const int c = (lane % C::LPR) ^ ((co / C::ZKD) & (C::LPR - 1));
             glds16(zrow + (size_t)co * zplane + c * 4, zb + q * 256);
         }
     } else {
-        for (int q = wid; q < C::COB; q += C::NW) {
-            const int col = (((lane >> 2) ^ (q & 15)) << 2) + (lane & 3);
-            const float* src = (w0 + col < T) ? zrow + (size_t)q * zplane + col : g_zero_page;
-            glds4(src, zb + q * C::CW);
+        for (int q = wid; q < C::COB * C::CW / 64; q += C::NW) {
+            const int co = q * C::ZKD + lane / C::CW, l = lane % C::CW;
+            const int col = (((l >> 2) ^ ((co / C::ZKD) & (C::LPR - 1))) << 2) + (l & 3);
+            const float* src = (w0 + col < T) ? zrow + (size_t)co * zplane + col : g_zero_page;
+            glds4(src, zb + q * 64);
         }
     }
     const int hbase = h0 + r0 - C::PH, wbase = w0 - (C::DILMAX ? (C::KW / 2) * A.dil : C::PW);
@@ -477,7 +482,7 @@ __global__ void __launch_bounds__(C::NT) wgrad_core(WgArgs A) {
     // per-lane LDS read bases.  A (dZ): channel = lane_j, 4 consecutive pixels per ds_read_b128; the k index of MFMA s
     // in pixel group g is pixel 8g + 4*lane_h + s for BOTH operands.
     const int zrowbase = ((wmw * C::MT) * 32 + lane_j) * C::CW;
-    const int zswz = lane_h ^ (lane_j & 15);
+    const int zswz = lane_h ^ ((lane_j / C::ZKD) & (C::LPR - 1));
     int xoff[C::NS];
 #pragma unroll
     for (int s = 0; s < C::NS; ++s) {
