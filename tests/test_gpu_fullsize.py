@@ -106,18 +106,28 @@ def test_dropout_rate_and_accumulation_full_size():
         assert ((v - 2 * u).norm() / u.norm().clamp_min(1e-30)).item() < 1e-6
 
 
-def test_finetune_shape_long_clip_direct_path():
-    """BASELINE config 4 shape: batch of one 30 s clip (T=1876, epochs.py:48-63).  Too many windows per row for the
-    frequency-domain kernels, so this exercises the direct MFMA kernels at a long, non-multiple-of-32 T."""
+@pytest.mark.parametrize("B,T", [(1, 1876), (2, 939)])
+def test_finetune_shape_long_clip_segmented_rows(B, T):
+    """BASELINE config 4 shape: batch of one 30 s clip (T=1876, epochs.py:48-63).  Rows longer than 12 windows are cut
+    into segments that run as separate spectral samples; checked against the direct MFMA kernels (activations,
+    gradients) and the naive kernels (embeddings) at a long, non-multiple-of-32 T."""
     from zeronotesamba_amd import _lib
-    B, T = 1, 1876
     model = build(3)
     x = synth(B, T, 4)
-    e_a, _, g_a = run(_lib.ZNS_IMPL_AUTO, model, x, B)
+    e_a, a_a, g_a = run(_lib.ZNS_IMPL_AUTO, model, x, B)
+    e_d, a_d, g_d = run(_lib.ZNS_IMPL_DIRECT, model, x, B)
     e_n, _, _ = run(_lib.ZNS_IMPL_NAIVE, model, x, B, backward=False)
-    assert tuple(e_a.shape) == (2, T)
+    assert tuple(e_a.shape) == (2 * B, T)
     assert (e_a - e_n).abs().max().item() < 1e-4
-    assert all(torch.isfinite(g).all().item() for g in g_a)
+    assert (e_a - e_d).abs().max().item() < 1e-4
+    for li in range(8):
+        scale = a_d[li].abs().max().item()
+        assert (a_a[li] - a_d[li]).abs().max().item() <= 1e-4 * scale, f"layer {li + 1} activations"
+    for ga, gd in zip(g_a, g_d):
+        rel = ((ga - gd).norm() / gd.norm().clamp_min(1e-30)).item()
+        assert rel < 1e-2, rel
+    # the segmented path is the frequency-domain one: a saved input spectrum exists for cv2..cv6
+    assert _lib.lib().zns_conv2d_spectrum_bytes(2, B, T, 128, 128, 9, 17, 32) > 0
 
 
 def test_clmr_style_shared_branch_module_api():

@@ -25,7 +25,7 @@
 
 namespace zns {
 
-constexpr int FN = 64, FF = 32, FDIL = 16;
+constexpr int FN = 64, FF = 32, FDIL = 12;
 constexpr int FS = 3 * FF;   // weight/spectrum slots per sample: (frequency f, Karatsuba part t) -> 3 f + t
 constexpr int FDILW = 12;   // backward-weights tiles keep two input-channel tiles in LDS: window count per row <= 12
 
@@ -54,16 +54,21 @@ __device__ __forceinline__ void twiddle_init(float2* tw) {
 //
 // x [nb, C, H, T] -> S [nb][FS][C][P].  Window b of a row starts at column b*V - off and has `valid` live samples
 // (64 for the overlapped correlation windows, V for the zero-padded blocks of backward-weights' dZ).
+//
+// Long rows are cut into NS segments of NB <= 12 windows each; a segment is a separate spectral "sample"
+// n' = n * NS + seg (the row taps of the GEMM stage are NB positions apart, so NB must stay small), NBT = windows
+// of the whole row.
 __global__ void __launch_bounds__(256) spec_fwd_kernel(const float* __restrict__ x, float* __restrict__ S, int C,
                                                        int H, int T, int V, int NB, int off, int valid, int chunks,
-                                                       float third_sign) {
+                                                       float third_sign, int NS, int NBT) {
     // Windows are staged through LDS so that global reads are coalesced: one wave-instruction fetches ONE window
     // (64 consecutive samples); all 64 fetches of a wave are issued before the first LDS write.  Each lane then
     // reads back its own window (row stride 65 floats: conflict free) and transforms it in registers.
     __shared__ float win[256 * (FN + 1)];
     const int CP = C * H * NB;
     const int chunk = blockIdx.x % chunks;
-    const int n = blockIdx.x / chunks;
+    const int ns = blockIdx.x / chunks;             // spectral sample = (sample, segment)
+    const int n = ns / NS, bseg = (ns - n * NS) * NB;
     const int lane = threadIdx.x & 63;
     const int wbase = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * 64);
     const float* xn = x + (size_t)n * C * H * T;
@@ -75,8 +80,8 @@ __global__ void __launch_bounds__(256) spec_fwd_kernel(const float* __restrict__
         int left = CP - qw;                           // windows that exist from here on
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
-            const int col = bb * V - off + lane;
-            xw[i] = (i < left && lane < valid && col >= 0 && col < T) ? xn[(size_t)R * T + col] : 0.f;
+            const int col = (bseg + bb) * V - off + lane;
+            xw[i] = (i < left && bseg + bb < NBT && lane < valid && col >= 0 && col < T) ? xn[(size_t)R * T + col] : 0.f;
             if (++bb == NB) { bb = 0; ++R; }
         }
     }
@@ -87,7 +92,7 @@ __global__ void __launch_bounds__(256) spec_fwd_kernel(const float* __restrict__
     if (q >= CP) return;
 #pragma unroll
     for (int m = 0; m < FN; ++m) xw[m] = win[threadIdx.x * (FN + 1) + m];
-    float* out = S + (size_t)n * FS * CP + q;
+    float* out = S + (size_t)ns * FS * CP + q;
     const size_t tstride = (size_t)CP;          // between consecutive slots
     float sr[FF], si[FF];
     rfft64(xw, sr, si);
@@ -127,18 +132,19 @@ static uint32_t div_magic(int d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32)
 
 template <int MODE>
 __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__ S, float* __restrict__ out, int C, int H,
-                                                       int T, int V, int NB, int chunks, int WPB, InvEpi E) {
+                                                       int T, int V, int NB, int chunks, int WPB, int NS, InvEpi E) {
     extern __shared__ __attribute__((aligned(16))) float stage[];   // [256][VS], VS odd: per-lane rows hit distinct banks
     const int pool = MODE == 1 ? E.pool : 1;
     const int Hq = H / pool;                       // output rows per channel (pooled rows in MODE 1)
     const int CP = C * H * NB;
     const int VS = V | 1;
     const int chunk = blockIdx.x % chunks;
-    const int n = blockIdx.x / chunks;
+    const int ns = blockIdx.x / chunks;             // spectral sample = (sample, segment)
+    const int n = ns / NS, bseg = (ns - n * NS) * NB;
     const int q0 = chunk * WPB;
     const int nwin = min(WPB, CP - q0);            // a multiple of pool * NB
     const unsigned tstride = (unsigned)CP * 4u;    // bytes between consecutive slots
-    float* sbase = const_cast<float*>(S) + (size_t)n * FS * CP;
+    float* sbase = const_cast<float*>(S) + (size_t)ns * FS * CP;
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(sbase, 0, (int)(tstride * FS), 0x00020000);
     if ((int)threadIdx.x < nwin) {
         const unsigned voff = (unsigned)(q0 + threadIdx.x) * 4u;
@@ -178,7 +184,7 @@ __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__
             const int e = e0 + u * 256;
             const int w = fastdiv(e, V, E.mV), v = e - w * V;          // pooled window inside the block, sample
             const int lg = fastdiv(w, NB, E.mNB), b = w - lg * NB;     // pooling group inside the block, window in its row
-            col[u] = b * V + v;
+            col[u] = (bseg + b) * V + v;
             ok[u] = e < nout && col[u] < T;
             Rq[u] = Rq0 + lg;                                          // = c * Hq + hq
             o[u] = ((size_t)n * C * Hq + Rq[u]) * T + col[u];
@@ -379,7 +385,13 @@ using FW5 = WgCfg<128, 256, 1, 3, 1, 2, 3, 2, 1, 1, FDILW, 4, 32>;
 using FW6 = WgCfg<256, 256, 1, 5, 1, 1, 5, 4, 1, 1, FDILW, 2, 32>;
 
 struct FftGeom {
-    int V, NB, P, nb;
+    int V;      // valid outputs per 64-sample window
+    int NBT;    // windows per image row
+    int NS;     // segments a row is cut into (each a separate spectral sample)
+    int NB;     // windows per segment (<= FDILW): the row taps of the GEMM stage are NB positions apart
+    int P;      // flattened (row, window) positions per channel of one spectral sample
+    int nb;     // spectral samples = nbr * B * NS
+    int Bs;     // spectral samples per branch = B * NS
 };
 
 static int fft_layer_of(const ConvArgs& a) {
@@ -395,19 +407,21 @@ static int fft_layer_of(const ConvArgs& a) {
 static FftGeom geom(const ConvArgs& a) {
     FftGeom g;
     g.V = FN - a.kw + 1;
-    g.NB = ceil_div(a.T, g.V);
+    g.NBT = ceil_div(a.T, g.V);
+    g.NS = ceil_div(g.NBT, FDILW);
+    g.NB = ceil_div(g.NBT, g.NS);
     g.P = a.H * g.NB;
-    g.nb = a.nbr * a.B;
+    g.Bs = a.B * g.NS;
+    g.nb = a.nbr * g.Bs;
     return g;
 }
 
 bool fft_supported(const ConvArgs& a) {
     if (fft_layer_of(a) < 0 || a.nbr < 1 || a.nbr > 2) return false;
-    const FftGeom g = geom(a);
-    return g.NB <= FDIL && a.T >= 32;
+    return a.T >= 32 && a.B >= 1;
 }
 
-bool fft_wgrad_supported(const ConvArgs& a) { return fft_supported(a) && geom(a).NB <= FDILW; }
+bool fft_wgrad_supported(const ConvArgs& a) { return fft_supported(a); }
 
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -418,6 +432,7 @@ struct FftWs {
 template <class W>
 static int fwg_pick_ks(const ConvArgs& a, const FftGeom& g, int* tiles_total, int* tps) {
     ConvArgs t = a;
+    t.B = g.Bs;          // every segment of every sample contributes K tiles
     t.T = g.P;           // K tiles run over the flattened axis
     t.nbr = a.nbr * FS;  // one accumulation per (branch, frequency, Karatsuba part)
     return wg_pick_ks<W>(t, tiles_total, tps);
@@ -464,7 +479,7 @@ static int run_spec_fwd(const float* x, float* S, int nb, int C, int H, int T, c
                         float third_sign, hipStream_t st) {
     const int chunks = ceil_div(C * g.P, 256);
     hipLaunchKernelGGL(spec_fwd_kernel, dim3((unsigned)((size_t)nb * chunks)), dim3(256), 0, st, x, S, C, H, T, g.V,
-                       g.NB, off, valid, chunks, third_sign);
+                       g.NB, off, valid, chunks, third_sign, g.NS, g.NBT);
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
 }
@@ -481,7 +496,7 @@ static int run_spec_inv(const float* S, float* out, int nb, int C, int H, int T,
     E.mHq = div_magic(H / pool);
     const size_t lds = (size_t)256 * (g.V | 1) * sizeof(float);
     hipLaunchKernelGGL(spec_inv_kernel<MODE>, dim3((unsigned)((size_t)nb * chunks)), dim3(256), lds, st, S, out, C, H, T,
-                       g.V, g.NB, chunks, WPB, E);
+                       g.V, g.NB, chunks, WPB, g.NS, E);
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
 }
@@ -525,7 +540,7 @@ static int run_fconv(const ConvArgs& a, const FftGeom& g, Ptr2 w, int transposed
     A.xmask = nullptr;
     A.inv_keep = 1.f;
     A.prev_pool = 1;
-    A.B = a.B;
+    A.B = g.Bs;
     A.T = g.P;
     A.N = g.nb * FS;
     A.F = FS;
@@ -609,7 +624,7 @@ static int fft_wgrad_t(const ConvArgs& a, const float* dz, const float* x, MPtr2
     if (rc) return rc;
     rc = run_spec_fwd(dz, sz, g.nb, a.cout, a.H, a.T, g, 0, g.V, -1.f, st);     // zero-padded V-blocks of dZ: (r, i, r-i)
     if (rc) return rc;
-    hipLaunchKernelGGL(spec_dc_sum_kernel, dim3(a.nbr * a.cout), dim3(256), 0, st, (const float*)sz, db, a.B, a.cout,
+    hipLaunchKernelGGL(spec_dc_sum_kernel, dim3(a.nbr * a.cout), dim3(256), 0, st, (const float*)sz, db, g.Bs, a.cout,
                        g.P, accumulate);
     ZNS_LAUNCH_CHECK();
     rc = set_lds_fw<W>(wgrad_core<W>);
@@ -618,7 +633,7 @@ static int fft_wgrad_t(const ConvArgs& a, const float* dz, const float* x, MPtr2
     A.dz = sz;
     A.x = sx;
     A.slab = slab;
-    A.B = a.B;
+    A.B = g.Bs;
     A.T = g.P;
     A.ncb = ceil_div(g.P, W::CW);
     A.F = FS;
