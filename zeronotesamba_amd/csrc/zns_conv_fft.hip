@@ -426,7 +426,7 @@ bool fft_wgrad_supported(const ConvArgs& a) { return fft_supported(a); }
 static size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct FftWs {
-    size_t s_in, s_out, z, wf, slab, total;
+    size_t s_in, s_out, wf, slab, total;
 };
 
 template <class W>
@@ -452,8 +452,7 @@ static FftWs fft_ws(const ConvArgs& a) {
     const size_t spec = (size_t)g.nb * FS * cmax * g.P * sizeof(float);
     w.s_in = 0;
     w.s_out = align_up(spec);
-    w.z = w.s_out + align_up(spec);
-    w.wf = w.z + align_up((size_t)g.nb * cmax * a.H * a.T * sizeof(float));
+    w.wf = w.s_out + align_up(spec);
     const size_t wfb = (size_t)a.nbr * FS * a.cout * a.cin * a.kh * sizeof(float);
     size_t slab = 0;
     switch (fft_layer_of(a)) {
@@ -565,7 +564,6 @@ static int fft_fwd_t(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float
     char* base = (char*)ws;
     float* s_in = xspec ? xspec : (float*)(base + L.s_in);   // kept by the caller for backward-weights when given
     float* s_out = (float*)(base + L.s_out);
-    float* z = (float*)(base + L.z);
     float* wf = (float*)(base + L.wf);
     int rc = run_spec_fwd(x, s_in, g.nb, a.cin, a.H, a.T, g, a.kw / 2, FN, 1.f, st);
     if (rc) return rc;
@@ -580,7 +578,6 @@ static int fft_fwd_t(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float
     E.inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
     E.seed = seed;
     E.layer = layer;
-    (void)z;
     return run_spec_inv<1>(s_out, y, g.nb, a.cout, a.H, a.T, g, E, st);
 }
 
@@ -593,7 +590,6 @@ static int fft_dgrad_t(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, co
     char* base = (char*)ws;
     float* s_in = (float*)(base + L.s_in);
     float* s_out = (float*)(base + L.s_out);
-    float* z = (float*)(base + L.z);
     float* wf = (float*)(base + L.wf);
     int rc = run_spec_fwd(dz, s_in, g.nb, a.cout, a.H, a.T, g, a.kw / 2, FN, 1.f, st);
     if (rc) return rc;
@@ -604,7 +600,6 @@ static int fft_dgrad_t(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, co
     E.inv_keep = inv_keep;
     E.prev_argmax = prev_argmax;
     E.prev_pool = prev_pool;
-    (void)z;
     return run_spec_inv<2>(s_out, dx, g.nb, a.cin, a.H, a.T, g, E, st);
 }
 
