@@ -31,15 +31,22 @@ __device__ __forceinline__ int acc_row(int reg, int lane_h) { return (reg & 3) +
 // =====================================================================================================
 // DILMAX > 0 selects the frequency-domain use of the core (see zns_conv_fft.hip): a 1-D correlation with KW taps
 // spaced `dil` (runtime, <= DILMAX) apart along the flattened (row, time-block) axis, weights chosen per frequency.
+//
+// HET selects the 12-wave layout for an 11-column-tile output (P = 352): a 4 x 11 grid of 32x32 tiles does not divide
+// over 4 SIMDs with equal waves, so waves 0..7 own (4 channel tiles x column tile w) and waves 8..11 own (channel
+// tile w-8 x column tiles 8, 9, 10): 2 x 4 + 3 = 11 tiles on every SIMD.
 template <int CIN_, int COUT_, int KH_, int KW_, int H_, int MT_, int RT_, int CT_, int WM_, int WR_, int WC_,
-          int CK_, int POOL_, int EPI_, int DILMAX_ = 0>
+          int CK_, int POOL_, int EPI_, int DILMAX_ = 0, int HET_ = 0>
 struct ConvCfg {
     static constexpr int DILMAX = DILMAX_;
+    static constexpr int HET = HET_;
+    static_assert(!HET || (MT_ == 4 && RT_ == 1 && CT_ == 1 && WM_ == 1 && WR_ == 1 && WC_ == 12 && KH_ == 1 && EPI_ == 1),
+                  "HET layout: 12 waves, 4 channel tiles, 11 column tiles");
     static constexpr int CIN = CIN_, COUT = COUT_, KH = KH_, KW = KW_, H = H_;
     static constexpr int MT = MT_, RT = RT_, CT = CT_, WM = WM_, WR = WR_, WC = WC_, CK = CK_;
     static constexpr int POOL = POOL_, EPI = EPI_;
     static constexpr int NW = WM * WR * WC, NT = NW * 64;
-    static constexpr int COB = WM * MT * 32, RB = WR * RT, WB = WC * CT * 32;
+    static constexpr int COB = WM * MT * 32, RB = WR * RT, WB = HET ? 11 * 32 : WC * CT * 32;
     static constexpr int PH = KH / 2, PW = KW / 2;
     // Patch rows start at a 16-byte aligned image column (w0 - pw rounded down to a multiple of 4) and are a
     // multiple of 4 floats long, so the patch can be staged with 16-byte LDS-DMA whenever T % 4 == 0.
@@ -171,6 +178,35 @@ __device__ __forceinline__ void compute_stage(const float* __restrict__ pa, cons
     }
 }
 
+// HET layout (see ConvCfg): one stage for a wave of type A (4 channel tiles x 1 column tile) or B (1 x 3).
+template <class C>
+__device__ __forceinline__ void compute_stage_het(const float* __restrict__ pa, const float* __restrict__ pb,
+                                                  f32x16 (&acc)[4], int dil, bool type_a) {
+    if (type_a) {
+#pragma unroll
+        for (int cp = 0; cp < C::CK / 2; ++cp)
+#pragma unroll
+            for (int s = 0; s < C::KW; ++s) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(pa + (cp * C::KW + s) * 256);
+                const float b = pb[2 * cp * C::PS + s * dil];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b, acc[m], 0, 0, 0);
+            }
+    } else {
+#pragma unroll
+        for (int cp = 0; cp < C::CK / 2; ++cp)
+#pragma unroll
+            for (int s = 0; s < C::KW; ++s) {
+                const float a = pa[(cp * C::KW + s) * 256];
+                float b[3];
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) b[ct] = pb[2 * cp * C::PS + ct * 32 + s * dil];
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[ct], acc[ct], 0, 0, 0);
+            }
+    }
+}
+
 template <class C>
 __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -210,9 +246,12 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) acc[m][rt][ct][k] = 0.f;
 
-    const int abase = wm * (64 * C::MT) + lane * C::MT;
+    const bool type_a = !C::HET || wid < 8;            // HET: waves 8..11 own one channel tile x column tiles 8..10
+    const int het_m0 = wid - 8;
     const int pw_al = (pw + 3) & ~3;   // patch origin = tile origin - pw_al (16-byte aligned); reads skip pw_al - pw
-    const int bbase = lane_h * C::PS + (wr * C::RT) * C::PCW + wc * C::CT * 32 + lane_j + (pw_al - pw);
+    const int abase = C::HET ? lane * 4 + (type_a ? 0 : het_m0) : wm * (64 * C::MT) + lane * C::MT;
+    const int bbase = C::HET ? lane_h * C::PS + (type_a ? wid : 8) * 32 + lane_j + (pw_al - pw)
+                             : lane_h * C::PS + (wr * C::RT) * C::PCW + wc * C::CT * 32 + lane_j + (pw_al - pw);
 
     PatchPlan<C> plan;
     patch_offsets<C>(plan, xn, h0, w0, T, wid, lane, pw_al,
@@ -229,8 +268,40 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
                 load_slab<C>(wbase + (size_t)(st + 1) * C::SLAB, slab(st + 1), wid, lane);
                 if (r == C::KH - 1) load_patch<C>(plan, xn, cc + 1, T, patch(cc + 1), wid);
             }
-            compute_stage<C>(slab(st) + abase, patch(cc) + bbase + r * C::PCW, acc, dil);
+            if constexpr (C::HET) {
+                f32x16(&hacc)[4] = *reinterpret_cast<f32x16(*)[4]>(&acc[0][0][0]);
+                compute_stage_het<C>(slab(st) + abase, patch(cc) + bbase, hacc, dil, type_a);
+            } else {
+                compute_stage<C>(slab(st) + abase, patch(cc) + bbase + r * C::PCW, acc, dil);
+            }
         }
+    }
+
+    if constexpr (C::HET) {
+        // tile t of this wave: type A -> (channel tile t, column tile wid); type B -> (channel tile wid-8, column tile 8+t)
+        const int pp = A.prev_pool;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (!type_a && t == 3) break;
+            const int co0 = cob * C::COB + (type_a ? t : het_m0) * 32;
+            const int col = w0 + (type_a ? wid : 8 + t) * 32 + lane_j;
+            if (col >= T) continue;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int co = co0 + acc_row(k, lane_h);
+                const size_t o = ((size_t)n * C::COUT + co) * T + col;
+                float g = acc[t][0][0][k];
+                if (A.xmask) g = (A.xmask[o] != 0.f) ? g * A.inv_keep : 0.f;
+                if (pp > 1) {
+                    const int am = A.prev_argmax[o];
+                    const size_t base = ((size_t)n * C::COUT + co) * pp * T + col;
+                    for (int a = 0; a < pp; ++a) A.dx[base + (size_t)a * T] = (a == am) ? g : 0.f;
+                } else {
+                    A.dx[o] = g;
+                }
+            }
+        }
+        return;
     }
 
     // ------------------------------------------------------------------ epilogue

@@ -366,10 +366,10 @@ __global__ void __launch_bounds__(256) spec_dc_sum_kernel(const float* __restric
 // =====================================================================================================
 //                                          instances + dispatch
 // =====================================================================================================
-//                  CIN COUT KH KW(taps) H  MT RT CT WM WR WC CK POOL EPI DILMAX
+//                  CIN COUT KH KW(taps) H  MT RT CT WM WR WC CK POOL EPI DILMAX HET
 using FF2 = ConvCfg<64, 64, 1, 7, 1, 2, 1, 2, 1, 1, 4, 8, 1, 1, FDIL>;
-using FF3 = ConvCfg<64, 128, 1, 5, 1, 4, 1, 1, 1, 1, 11, 8, 1, 1, FDIL>;
-using FF4 = ConvCfg<128, 128, 1, 9, 1, 4, 1, 1, 1, 1, 11, 8, 1, 1, FDIL>;
+using FF3 = ConvCfg<64, 128, 1, 5, 1, 4, 1, 1, 1, 1, 12, 8, 1, 1, FDIL, 1>;
+using FF4 = ConvCfg<128, 128, 1, 9, 1, 4, 1, 1, 1, 1, 12, 8, 1, 1, FDIL, 1>;
 using FF5 = ConvCfg<128, 256, 1, 3, 1, 2, 1, 1, 4, 1, 3, 16, 1, 1, FDIL>;
 using FF6 = ConvCfg<256, 256, 1, 5, 1, 2, 1, 1, 4, 1, 3, 8, 1, 1, FDIL>;
 using FD2 = FF2;
