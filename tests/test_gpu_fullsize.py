@@ -130,6 +130,27 @@ def test_finetune_shape_long_clip_segmented_rows(B, T):
     assert _lib.lib().zns_conv2d_spectrum_bytes(2, B, T, 128, 128, 9, 17, 32) > 0
 
 
+@pytest.mark.parametrize("B,T", [(1, 32), (3, 45), (2, 100), (5, 577), (1, 1000), (2, 529)])
+def test_ragged_shapes_spectral_vs_direct(B, T):
+    """Ragged batch sizes and row lengths: T below one window (32), odd T (no 16-byte alignment anywhere), T just past
+    a segment boundary (cv2: 12 windows of 52 = 624 > 577 > 11*52; cv6: 577 = 13.1 windows -> 2 segments), T = 529 =
+    one sample past 12 windows of cv6 (44*12 = 528) and a long row with 3 segments.  Default (frequency-domain) path
+    against the direct MFMA kernels: activations of every layer, embeddings, every gradient."""
+    from zeronotesamba_amd import _lib
+    model = build(11)
+    x = synth(B, T, 100 + T)
+    e_f, a_f, g_f = run(_lib.ZNS_IMPL_AUTO, model, x, B)
+    e_d, a_d, g_d = run(_lib.ZNS_IMPL_DIRECT, model, x, B)
+    assert tuple(e_f.shape) == (2 * B, T)
+    assert (e_f - e_d).abs().max().item() < 1e-4
+    for li in range(8):
+        scale = a_d[li].abs().max().item()
+        assert (a_f[li] - a_d[li]).abs().max().item() <= 1e-4 * scale, f"layer {li + 1} activations"
+    for gf, gd in zip(g_f, g_d):
+        rel = ((gf - gd).norm() / gd.norm().clamp_min(1e-30)).item()
+        assert rel < 1e-2, rel
+
+
 def test_clmr_style_shared_branch_module_api():
     """pretext.py:494-511 ("clmr"): ONE DS_CNN applied to two views; its weight gradient is the sum of both passes."""
     from zeronotesamba_amd.models.loss_functions import NTXent
