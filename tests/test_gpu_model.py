@@ -210,3 +210,40 @@ def test_frozen_backbone_gets_no_conv_grads():
     o.sum().backward()
     assert d.pretext.anchor.pretrained.cv4.weight.grad is None
     assert d.pretext.anchor.fc1.weight.grad is not None and d.pretext.postve.fc1.bias.grad is not None
+
+
+def test_config1_sample_script_plumbing():
+    """BASELINE configs[0] (sample_script.py:31-48): two 10 s stems -> generate_XQT x2 -> reshape (1,1,96,T) ->
+    Down_CNN().eval(): percussive = pretext.postve(vqt_postve), non_percussive = pretext.anchor(vqt_anchor),
+    combined = model(anchor, postve); every output is (1, 626).  Whole pipeline on the device against the whole
+    pipeline on the oracle (numpy VQT restatement + stock-torch CNN)."""
+    import zeronotesamba_amd.processing.input_rep as IR
+    from oracle import vqt_ref
+    from zeronotesamba_amd.models.models import Down_CNN
+    rng = np.random.default_rng(0)
+    n = 160000
+    t = np.arange(n) / 16000.0
+    other = (0.1 * rng.standard_normal(n) + 0.3 * np.sin(2 * np.pi * 220 * t) + 0.2 * np.sin(2 * np.pi * 1760 * t)).astype(np.float32)
+    drums = (0.1 * rng.standard_normal(n) * (np.sin(2 * np.pi * 2 * t) > 0.9) + 0.05 * np.sin(2 * np.pi * 60 * t)).astype(np.float32)
+    vqt_postve = torch.from_numpy(IR.generate_XQT(drums, 16000, "vqt"))
+    vqt_anchor = torch.from_numpy(IR.generate_XQT(other, 16000, "vqt"))
+    assert tuple(vqt_postve.shape) == (96, 626)
+    vqt_postve = vqt_postve.reshape(1, 1, vqt_postve.shape[0], vqt_postve.shape[1])
+    vqt_anchor = vqt_anchor.reshape(1, 1, vqt_anchor.shape[0], vqt_anchor.shape[1])
+    sd = cnn_ref.synth_state_dict(21, 2.0)
+    model = Down_CNN()
+    model.pretext.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        percussive = model.pretext.postve(vqt_postve.float().to(DEV))
+        non_percussive = model.pretext.anchor(vqt_anchor.float().to(DEV))
+        combined = model(vqt_anchor.float().to(DEV), vqt_postve.float().to(DEV))
+    assert tuple(percussive.shape) == tuple(non_percussive.shape) == tuple(combined.shape) == (1, 626)
+    assert torch.equal(combined, torch.maximum(non_percussive, percussive))
+    # oracle pipeline
+    ra = torch.from_numpy(vqt_ref.generate_XQT(other, 16000, "vqt")).reshape(1, 1, 96, 626)
+    rp = torch.from_numpy(vqt_ref.generate_XQT(drums, 16000, "vqt")).reshape(1, 1, 96, 626)
+    with torch.no_grad():
+        want = cnn_ref.down_forward({"pretext." + k: v for k, v in sd.items()}, ra, rp)
+    err = (combined.cpu() - want).abs().max().item()
+    assert err < 1e-4, err
