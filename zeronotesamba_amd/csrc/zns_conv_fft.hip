@@ -372,6 +372,15 @@ using FF3 = ConvCfg<64, 128, 1, 5, 1, 4, 1, 1, 1, 1, 12, 8, 1, 1, FDIL, 1>;
 using FF4 = ConvCfg<128, 128, 1, 9, 1, 4, 1, 1, 1, 1, 12, 8, 1, 1, FDIL, 1>;
 using FF5 = ConvCfg<128, 256, 1, 3, 1, 2, 1, 1, 4, 1, 3, 16, 1, 1, FDIL>;
 using FF6 = ConvCfg<256, 256, 1, 5, 1, 2, 1, 1, 4, 1, 3, 8, 1, 1, FDIL>;
+// narrower variants for short flattened axes (e.g. T = 313 / 626: P = 224 for cv3/cv4, 56..64 for cv5/cv6)
+using FF3a = ConvCfg<64, 128, 1, 5, 1, 4, 1, 1, 1, 1, 8, 8, 1, 1, FDIL>;
+using FF4a = ConvCfg<128, 128, 1, 9, 1, 4, 1, 1, 1, 1, 8, 8, 1, 1, FDIL>;
+using FF5a = ConvCfg<128, 256, 1, 3, 1, 2, 1, 1, 4, 1, 2, 16, 1, 1, FDIL>;
+using FF6a = ConvCfg<256, 256, 1, 5, 1, 2, 1, 1, 4, 1, 2, 8, 1, 1, FDIL>;
+using FD3a = ConvCfg<128, 64, 1, 5, 1, 2, 1, 1, 1, 1, 8, 8, 1, 1, FDIL>;
+using FD4a = FF4a;
+using FD5a = ConvCfg<256, 128, 1, 3, 1, 1, 1, 1, 4, 1, 2, 16, 1, 1, FDIL>;
+using FD6a = FF6a;
 using FD2 = FF2;
 using FD3 = ConvCfg<128, 64, 1, 5, 1, 2, 1, 1, 1, 1, 11, 8, 1, 1, FDIL>;
 using FD4 = FF4;
@@ -649,14 +658,29 @@ static int fft_wgrad_t(const ConvArgs& a, const float* dz, const float* x, MPtr2
     return ZNS_OK;
 }
 
+// true when the narrow workgroup (WBa columns) covers the flattened axis with fewer padded columns than the wide one
+template <class Wide, class Narrow>
+static bool use_narrow(const ConvArgs& a) {
+    const int P = geom(a).P;
+    return (long long)ceil_div(P, Narrow::WB) * Narrow::WB < (long long)ceil_div(P, Wide::WB) * Wide::WB;
+}
+
 int fft_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, uint8_t* argmax, float drop_p,
             uint32_t seed, int layer, float* xspec, void* ws, size_t ws_bytes, hipStream_t st) {
     switch (fft_layer_of(a)) {
         case 2: return fft_fwd_t<FF2>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
-        case 3: return fft_fwd_t<FF3>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
-        case 4: return fft_fwd_t<FF4>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
-        case 5: return fft_fwd_t<FF5>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
-        case 6: return fft_fwd_t<FF6>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
+        case 3:
+            if (use_narrow<FF3, FF3a>(a)) return fft_fwd_t<FF3a>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
+            return fft_fwd_t<FF3>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
+        case 4:
+            if (use_narrow<FF4, FF4a>(a)) return fft_fwd_t<FF4a>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
+            return fft_fwd_t<FF4>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
+        case 5:
+            if (use_narrow<FF5, FF5a>(a)) return fft_fwd_t<FF5a>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
+            return fft_fwd_t<FF5>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
+        case 6:
+            if (use_narrow<FF6, FF6a>(a)) return fft_fwd_t<FF6a>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
+            return fft_fwd_t<FF6>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
     }
     return ZNS_ERR_ARG;
 }
@@ -665,10 +689,18 @@ int fft_dgrad(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, const float
               const uint8_t* prev_argmax, int prev_pool, void* ws, size_t ws_bytes, hipStream_t st) {
     switch (fft_layer_of(a)) {
         case 2: return fft_dgrad_t<FD2>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
-        case 3: return fft_dgrad_t<FD3>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
-        case 4: return fft_dgrad_t<FD4>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
-        case 5: return fft_dgrad_t<FD5>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
-        case 6: return fft_dgrad_t<FD6>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
+        case 3:
+            if (use_narrow<FD3, FD3a>(a)) return fft_dgrad_t<FD3a>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
+            return fft_dgrad_t<FD3>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
+        case 4:
+            if (use_narrow<FD4, FD4a>(a)) return fft_dgrad_t<FD4a>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
+            return fft_dgrad_t<FD4>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
+        case 5:
+            if (use_narrow<FD5, FD5a>(a)) return fft_dgrad_t<FD5a>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
+            return fft_dgrad_t<FD5>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
+        case 6:
+            if (use_narrow<FD6, FD6a>(a)) return fft_dgrad_t<FD6a>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
+            return fft_dgrad_t<FD6>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
     }
     return ZNS_ERR_ARG;
 }
