@@ -70,6 +70,10 @@ size_t zns_conv2d_workspace_bytes(int nbr, int B, int T, int cin, int cout, int 
 /* Bytes of the input spectrum the forward pass can hand to backward-weights (0 when this geometry does not use
  * the frequency-domain kernels): pass a buffer of that size as `xspec` to BOTH calls to skip recomputing it. */
 size_t zns_conv2d_spectrum_bytes(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H);
+/* Bytes of the dZ spectrum backward-weights can hand to backward-data of the same layer (0 when the geometry does
+ * not use the frequency-domain kernels): pass a buffer of that size as `dzspec_out` to zns_conv2d_wgrad_f32 and
+ * then as `dzspec` to zns_conv2d_dgrad_f32 -- dZ is then read and transformed once for both. */
+size_t zns_conv2d_dz_spectrum_bytes(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H);
 
 int zns_conv2d_fwd_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, int pool,
                        const float* x, const float* const* w, const float* const* bias,
@@ -91,6 +95,7 @@ int zns_conv2d_fwd_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw,
 int zns_conv2d_dgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H,
                          const float* dz, const float* const* w, float* dx,
                          const float* x, float inv_keep, const uint8_t* prev_argmax, int prev_pool,
+                         const float* dzspec /* nullable: dZ spectrum left by zns_conv2d_wgrad_f32 */,
                          void* ws, size_t ws_bytes, void* stream);
 
 /* Backward-weights: dw[br] (+)= sum_{b,h,t} dz (x) shifted x ; db[br] (+)= sum dz.
@@ -98,6 +103,7 @@ int zns_conv2d_dgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int k
 int zns_conv2d_wgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H,
                          const float* dz, const float* x, float* const* dw, float* const* db,
                          int accumulate, const float* xspec /* nullable: spectrum saved by the forward call */,
+                         float* dzspec_out /* nullable: receives the dZ spectrum, see zns_conv2d_dz_spectrum_bytes */,
                          void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ DS_CNN head

@@ -127,6 +127,20 @@ def test_conv_layer(li, impl, T):
             # no-mask variant
             dx2 = _ops.conv_dgrad(li, nbr, B, T, dzd, wd, None, 1.0, None, 1, ws)
             close(dx2, xg.grad, what=f"{name} dgrad (no epilogue)")
+            # shared dZ spectrum: backward-weights transforms dZ once for itself AND for the backward-data call;
+            # same arithmetic as the two separate transforms, so both results must be bitwise unchanged
+            dzs = _ops.dz_spectrum(li, nbr, B, T, dev)
+            assert (dzs is not None) == (impl == "auto" and spec is not None)
+            if dzs is not None:
+                dw3 = [torch.zeros_like(t) for t in wd]
+                db3 = [torch.zeros_like(t) for t in bd]
+                dw1 = [torch.zeros_like(t) for t in wd]
+                db1 = [torch.zeros_like(t) for t in bd]
+                _ops.conv_wgrad(li, nbr, B, T, dzd, xd, dw1, db1, False, ws, xspec=spec)
+                _ops.conv_wgrad(li, nbr, B, T, dzd, xd, dw3, db3, False, ws, xspec=spec, dzspec_out=dzs)
+                dx3 = _ops.conv_dgrad(li, nbr, B, T, dzd, wd, xd, inv_keep, pam, prev_pool, ws, dzspec=dzs)
+                assert all(torch.equal(u, v) for u, v in zip(dw1 + db1, dw3 + db3)), f"{name} wgrad with dzspec_out"
+                assert torch.equal(dx3, dx), f"{name} dgrad from the shared dZ spectrum"
         torch.cuda.synchronize()
     finally:
         L.zns_set_impl(prev)

@@ -86,13 +86,14 @@ def conv_fwd(li: int, nbr: int, B: int, T: int, x: torch.Tensor, w: Sequence[tor
 
 def conv_dgrad(li: int, nbr: int, B: int, T: int, dz: torch.Tensor, w: Sequence[torch.Tensor],
                x: Optional[torch.Tensor], inv_keep: float, prev_argmax: Optional[torch.Tensor], prev_pool: int,
-               ws: torch.Tensor) -> torch.Tensor:
+               ws: torch.Tensor, dzspec: Optional[torch.Tensor] = None) -> torch.Tensor:
     name, cin, cout, kh, kw, pool = LAYERS[li]
     H = H_IN[li]
     dx = torch.empty((nbr * B, cin, H * prev_pool, T), dtype=torch.float32, device=dz.device)
     rc = _lib.lib().zns_conv2d_dgrad_f32(nbr, B, T, cin, cout, kh, kw, H, dz.data_ptr(), _pp(w), dx.data_ptr(),
                                          x.data_ptr() if x is not None else None, float(inv_keep),
                                          prev_argmax.data_ptr() if prev_argmax is not None else None, prev_pool,
+                                         dzspec.data_ptr() if dzspec is not None else None,
                                          ws.data_ptr(), ws.numel(), stream_ptr())
     _lib.check(rc, f"zns_conv2d_dgrad_f32[{name}]")
     return dx
@@ -100,14 +101,22 @@ def conv_dgrad(li: int, nbr: int, B: int, T: int, dz: torch.Tensor, w: Sequence[
 
 def conv_wgrad(li: int, nbr: int, B: int, T: int, dz: torch.Tensor, x: torch.Tensor, dw: Sequence[torch.Tensor],
                db: Sequence[torch.Tensor], accumulate: bool, ws: torch.Tensor,
-               xspec: Optional[torch.Tensor] = None) -> None:
+               xspec: Optional[torch.Tensor] = None, dzspec_out: Optional[torch.Tensor] = None) -> None:
     name, cin, cout, kh, kw, pool = LAYERS[li]
     H = H_IN[li]
     rc = _lib.lib().zns_conv2d_wgrad_f32(nbr, B, T, cin, cout, kh, kw, H, dz.data_ptr(), x.data_ptr(), _pp(dw),
                                          _pp(db), int(bool(accumulate)),
                                          xspec.data_ptr() if xspec is not None else None,
+                                         dzspec_out.data_ptr() if dzspec_out is not None else None,
                                          ws.data_ptr(), ws.numel(), stream_ptr())
     _lib.check(rc, f"zns_conv2d_wgrad_f32[{name}]")
+
+
+def dz_spectrum(li: int, nbr: int, B: int, T: int, device) -> Optional[torch.Tensor]:
+    """Scratch for the dZ spectrum backward-weights hands to backward-data of the same layer (None: not applicable)."""
+    name, cin, cout, kh, kw, pool = LAYERS[li]
+    n = _lib.lib().zns_conv2d_dz_spectrum_bytes(nbr, B, T, cin, cout, kh, kw, H_IN[li])
+    return torch.empty(n // 4, dtype=torch.float32, device=device) if n else None
 
 
 def head_fwd(nbr: int, B: int, T: int, h: torch.Tensor, w: Sequence[torch.Tensor], b: Sequence[torch.Tensor]):
@@ -201,11 +210,12 @@ def stack_backward(x: torch.Tensor, P: StackParams, B: int, acts: List[torch.Ten
         return
     for li in range(7, 0, -1):
         xin = acts[li - 1]
-        conv_wgrad(li, nbr, B, T, dz, xin, G.conv_w[li], G.conv_b[li], accumulate, ws, argm.get(100 + li))
+        dzs = dz_spectrum(li, nbr, B, T, dz.device)     # dZ is transformed once for both calls below
+        conv_wgrad(li, nbr, B, T, dz, xin, G.conv_w[li], G.conv_b[li], accumulate, ws, argm.get(100 + li), dzs)
         if after_layer:
             after_layer(LAYERS[li][0])
         prev_pool = LAYERS[li - 1][5]
-        dz = conv_dgrad(li, nbr, B, T, dz, P.conv_w[li], xin, inv_keep, argm.get(li - 1), prev_pool, ws)
+        dz = conv_dgrad(li, nbr, B, T, dz, P.conv_w[li], xin, inv_keep, argm.get(li - 1), prev_pool, ws, dzs)
     conv_wgrad(0, nbr, B, T, dz, x, G.conv_w[0], G.conv_b[0], accumulate, ws)
     if after_layer:
         after_layer("cv1")

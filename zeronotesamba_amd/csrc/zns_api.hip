@@ -69,6 +69,11 @@ size_t zns_conv2d_spectrum_bytes(int nbr, int B, int T, int cin, int cout, int k
     return (g_impl == ZNS_IMPL_AUTO && fft_wgrad_supported(a)) ? fft_spectrum_bytes(a) : 0;
 }
 
+size_t zns_conv2d_dz_spectrum_bytes(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H) {
+    ConvArgs a{nbr, B, T, cin, cout, kh, kw, H, 1};
+    return (g_impl == ZNS_IMPL_AUTO && fft_wgrad_supported(a)) ? fft_dz_spectrum_bytes(a) : 0;
+}
+
 int zns_conv2d_fwd_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, int pool, const float* x,
                        const float* const* w, const float* const* bias, float* y, uint8_t* argmax, float drop_p,
                        uint32_t seed, int layer, float* xspec, void* ws, size_t ws_bytes, void* stream) {
@@ -90,7 +95,8 @@ int zns_conv2d_fwd_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw,
 
 int zns_conv2d_dgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, const float* dz,
                          const float* const* w, float* dx, const float* x, float inv_keep,
-                         const uint8_t* prev_argmax, int prev_pool, void* ws, size_t ws_bytes, void* stream) {
+                         const uint8_t* prev_argmax, int prev_pool, const float* dzspec, void* ws, size_t ws_bytes,
+                         void* stream) {
     ConvArgs a{nbr, B, T, cin, cout, kh, kw, H, 1};
     int rc = check_conv(a, "conv2d_dgrad");
     if (rc) return rc;
@@ -100,7 +106,7 @@ int zns_conv2d_dgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int k
     hipStream_t st = (hipStream_t)stream;
     if (g_impl == ZNS_IMPL_NAIVE) return naive_dgrad(a, dz, pw, dx, x, inv_keep, prev_argmax, prev_pool, st);
     if (g_impl == ZNS_IMPL_AUTO && fft_supported(a))
-        return fft_dgrad(a, dz, pw, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
+        return fft_dgrad(a, dz, pw, dx, x, inv_keep, prev_argmax, prev_pool, dzspec, ws, ws_bytes, st);
     if (mfma_supported(a)) return mfma_dgrad(a, dz, pw, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
     set_error("conv2d_dgrad: no gfx950 kernel instance for cin=%d cout=%d k=%dx%d H=%d", cin, cout, kh, kw, H);
     return ZNS_ERR_ARG;
@@ -108,7 +114,7 @@ int zns_conv2d_dgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int k
 
 int zns_conv2d_wgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, const float* dz,
                          const float* x, float* const* dw, float* const* db, int accumulate, const float* xspec,
-                         void* ws, size_t ws_bytes, void* stream) {
+                         float* dzspec_out, void* ws, size_t ws_bytes, void* stream) {
     ConvArgs a{nbr, B, T, cin, cout, kh, kw, H, 1};
     int rc = check_conv(a, "conv2d_wgrad");
     if (rc) return rc;
@@ -122,7 +128,7 @@ int zns_conv2d_wgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int k
     }
     if (is_cv1(a)) return cv1_wgrad(a, dz, x, pdw, pdb, accumulate, ws, ws_bytes, st);
     if (g_impl == ZNS_IMPL_AUTO && fft_wgrad_supported(a))
-        return fft_wgrad(a, dz, x, pdw, pdb, accumulate, xspec, ws, ws_bytes, st);
+        return fft_wgrad(a, dz, x, pdw, pdb, accumulate, xspec, dzspec_out, ws, ws_bytes, st);
     if (mfma_supported(a)) {
         rc = mfma_wgrad(a, dz, x, pdw, accumulate, ws, ws_bytes, st);
         if (rc) return rc;

@@ -60,7 +60,7 @@ __device__ __forceinline__ void twiddle_init(float2* tw) {
 // of the whole row.
 __global__ void __launch_bounds__(256) spec_fwd_kernel(const float* __restrict__ x, float* __restrict__ S, int C,
                                                        int H, int T, int V, int NB, int off, int valid, int chunks,
-                                                       float third_sign, int NS, int NBT) {
+                                                       float third_sign, int NS, int NBT, float* __restrict__ S2) {
     // Windows are staged through LDS so that global reads are coalesced: one wave-instruction fetches ONE window
     // (64 consecutive samples); all 64 fetches of a wave are issued before the first LDS write.  Each lane then
     // reads back its own window (row stride 65 floats: conflict free) and transforms it in registers.
@@ -101,6 +101,20 @@ __global__ void __launch_bounds__(256) spec_fwd_kernel(const float* __restrict__
         out[(3 * f) * tstride] = sr[f];
         out[(3 * f + 1) * tstride] = si[f];
         out[(3 * f + 2) * tstride] = f ? sr[f] + third_sign * si[f] : 0.f;
+    }
+    if (S2 != nullptr) {
+        // second spectrum from the same staged samples: the zero-padded V-block of backward-weights is samples
+        // [off, off + V) of the overlapped window (both start V apart; off = kw/2), planes (re, im, re - im)
+#pragma unroll
+        for (int m = 0; m < FN; ++m) xw[m] = (m < V) ? win[threadIdx.x * (FN + 1) + m + off] : 0.f;
+        rfft64(xw, sr, si);
+        float* out2 = S2 + (size_t)ns * FS * CP + q;
+#pragma unroll
+        for (int f = 0; f < FF; ++f) {
+            out2[(3 * f) * tstride] = sr[f];
+            out2[(3 * f + 1) * tstride] = si[f];
+            out2[(3 * f + 2) * tstride] = f ? sr[f] - si[f] : 0.f;
+        }
     }
 }
 
@@ -482,12 +496,16 @@ size_t fft_spectrum_bytes(const ConvArgs& a) {
     const FftGeom g = geom(a);
     return (size_t)g.nb * FS * a.cin * g.P * sizeof(float);
 }
+size_t fft_dz_spectrum_bytes(const ConvArgs& a) {
+    const FftGeom g = geom(a);
+    return (size_t)g.nb * FS * a.cout * g.P * sizeof(float);
+}
 
 static int run_spec_fwd(const float* x, float* S, int nb, int C, int H, int T, const FftGeom& g, int off, int valid,
-                        float third_sign, hipStream_t st) {
+                        float third_sign, hipStream_t st, float* S2 = nullptr) {
     const int chunks = ceil_div(C * g.P, 256);
     hipLaunchKernelGGL(spec_fwd_kernel, dim3((unsigned)((size_t)nb * chunks)), dim3(256), 0, st, x, S, C, H, T, g.V,
-                       g.NB, off, valid, chunks, third_sign, g.NS, g.NBT);
+                       g.NB, off, valid, chunks, third_sign, g.NS, g.NBT, S2);
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
 }
@@ -592,7 +610,8 @@ static int fft_fwd_t(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float
 
 template <class C>
 static int fft_dgrad_t(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, const float* x, float inv_keep,
-                       const uint8_t* prev_argmax, int prev_pool, void* ws, size_t ws_bytes, hipStream_t st) {
+                       const uint8_t* prev_argmax, int prev_pool, const float* dzspec, void* ws, size_t ws_bytes,
+                       hipStream_t st) {
     const FftGeom g = geom(a);
     const FftWs L = fft_ws(a);
     if (ws_bytes < L.total) { set_error("conv dgrad (fft): workspace %zu < %zu", ws_bytes, L.total); return ZNS_ERR_WORKSPACE; }
@@ -600,7 +619,9 @@ static int fft_dgrad_t(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, co
     float* s_in = (float*)(base + L.s_in);
     float* s_out = (float*)(base + L.s_out);
     float* wf = (float*)(base + L.wf);
-    int rc = run_spec_fwd(dz, s_in, g.nb, a.cout, a.H, a.T, g, a.kw / 2, FN, 1.f, st);
+    int rc = ZNS_OK;
+    if (dzspec) s_in = const_cast<float*>(dzspec);           // written by the preceding backward-weights call
+    else rc = run_spec_fwd(dz, s_in, g.nb, a.cout, a.H, a.T, g, a.kw / 2, FN, 1.f, st);
     if (rc) return rc;
     rc = run_fconv<C>(a, g, w, 1, s_in, s_out, wf, 1, st);
     if (rc) return rc;
@@ -614,7 +635,7 @@ static int fft_dgrad_t(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, co
 
 template <class W>
 static int fft_wgrad_t(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, MPtr2 db, int accumulate,
-                       const float* xspec, void* ws, size_t ws_bytes, hipStream_t st) {
+                       const float* xspec, float* dzspec_out, void* ws, size_t ws_bytes, hipStream_t st) {
     const FftGeom g = geom(a);
     const FftWs L = fft_ws(a);
     if (ws_bytes < L.total) { set_error("conv wgrad (fft): workspace %zu < %zu", ws_bytes, L.total); return ZNS_ERR_WORKSPACE; }
@@ -626,7 +647,10 @@ static int fft_wgrad_t(const ConvArgs& a, const float* dz, const float* x, MPtr2
     if (xspec) sx = const_cast<float*>(xspec);                                         // saved by the forward call
     else rc = run_spec_fwd(x, sx, g.nb, a.cin, a.H, a.T, g, a.kw / 2, FN, 1.f, st);   // windows of the input: (xr, xi, xr+xi)
     if (rc) return rc;
-    rc = run_spec_fwd(dz, sz, g.nb, a.cout, a.H, a.T, g, 0, g.V, -1.f, st);     // zero-padded V-blocks of dZ: (r, i, r-i)
+    if (dzspec_out)   // one pass over dZ: overlapped windows for the backward-data call + the zero-padded V-blocks
+        rc = run_spec_fwd(dz, dzspec_out, g.nb, a.cout, a.H, a.T, g, a.kw / 2, FN, 1.f, st, sz);
+    else
+        rc = run_spec_fwd(dz, sz, g.nb, a.cout, a.H, a.T, g, 0, g.V, -1.f, st);  // zero-padded V-blocks of dZ: (r, i, r-i)
     if (rc) return rc;
     hipLaunchKernelGGL(spec_dc_sum_kernel, dim3(a.nbr * a.cout), dim3(256), 0, st, (const float*)sz, db, g.Bs, a.cout,
                        g.P, accumulate);
@@ -686,33 +710,33 @@ int fft_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, uint
 }
 
 int fft_dgrad(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, const float* x, float inv_keep,
-              const uint8_t* prev_argmax, int prev_pool, void* ws, size_t ws_bytes, hipStream_t st) {
+              const uint8_t* prev_argmax, int prev_pool, const float* dzspec, void* ws, size_t ws_bytes, hipStream_t st) {
     switch (fft_layer_of(a)) {
-        case 2: return fft_dgrad_t<FD2>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
+        case 2: return fft_dgrad_t<FD2>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, dzspec, ws, ws_bytes, st);
         case 3:
-            if (use_narrow<FD3, FD3a>(a)) return fft_dgrad_t<FD3a>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
-            return fft_dgrad_t<FD3>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
+            if (use_narrow<FD3, FD3a>(a)) return fft_dgrad_t<FD3a>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, dzspec, ws, ws_bytes, st);
+            return fft_dgrad_t<FD3>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, dzspec, ws, ws_bytes, st);
         case 4:
-            if (use_narrow<FD4, FD4a>(a)) return fft_dgrad_t<FD4a>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
-            return fft_dgrad_t<FD4>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
+            if (use_narrow<FD4, FD4a>(a)) return fft_dgrad_t<FD4a>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, dzspec, ws, ws_bytes, st);
+            return fft_dgrad_t<FD4>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, dzspec, ws, ws_bytes, st);
         case 5:
-            if (use_narrow<FD5, FD5a>(a)) return fft_dgrad_t<FD5a>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
-            return fft_dgrad_t<FD5>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
+            if (use_narrow<FD5, FD5a>(a)) return fft_dgrad_t<FD5a>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, dzspec, ws, ws_bytes, st);
+            return fft_dgrad_t<FD5>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, dzspec, ws, ws_bytes, st);
         case 6:
-            if (use_narrow<FD6, FD6a>(a)) return fft_dgrad_t<FD6a>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
-            return fft_dgrad_t<FD6>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
+            if (use_narrow<FD6, FD6a>(a)) return fft_dgrad_t<FD6a>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, dzspec, ws, ws_bytes, st);
+            return fft_dgrad_t<FD6>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, dzspec, ws, ws_bytes, st);
     }
     return ZNS_ERR_ARG;
 }
 
 int fft_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, MPtr2 db, int accumulate,
-              const float* xspec, void* ws, size_t ws_bytes, hipStream_t st) {
+              const float* xspec, float* dzspec_out, void* ws, size_t ws_bytes, hipStream_t st) {
     switch (fft_layer_of(a)) {
-        case 2: return fft_wgrad_t<FW2>(a, dz, x, dw, db, accumulate, xspec, ws, ws_bytes, st);
-        case 3: return fft_wgrad_t<FW3>(a, dz, x, dw, db, accumulate, xspec, ws, ws_bytes, st);
-        case 4: return fft_wgrad_t<FW4>(a, dz, x, dw, db, accumulate, xspec, ws, ws_bytes, st);
-        case 5: return fft_wgrad_t<FW5>(a, dz, x, dw, db, accumulate, xspec, ws, ws_bytes, st);
-        case 6: return fft_wgrad_t<FW6>(a, dz, x, dw, db, accumulate, xspec, ws, ws_bytes, st);
+        case 2: return fft_wgrad_t<FW2>(a, dz, x, dw, db, accumulate, xspec, dzspec_out, ws, ws_bytes, st);
+        case 3: return fft_wgrad_t<FW3>(a, dz, x, dw, db, accumulate, xspec, dzspec_out, ws, ws_bytes, st);
+        case 4: return fft_wgrad_t<FW4>(a, dz, x, dw, db, accumulate, xspec, dzspec_out, ws, ws_bytes, st);
+        case 5: return fft_wgrad_t<FW5>(a, dz, x, dw, db, accumulate, xspec, dzspec_out, ws, ws_bytes, st);
+        case 6: return fft_wgrad_t<FW6>(a, dz, x, dw, db, accumulate, xspec, dzspec_out, ws, ws_bytes, st);
     }
     return ZNS_ERR_ARG;
 }

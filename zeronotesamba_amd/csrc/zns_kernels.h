@@ -42,12 +42,13 @@ bool fft_supported(const ConvArgs& a);
 bool fft_wgrad_supported(const ConvArgs& a);
 size_t fft_workspace_bytes(const ConvArgs& a);
 size_t fft_spectrum_bytes(const ConvArgs& a);   // input spectrum shared by forward and backward-weights
+size_t fft_dz_spectrum_bytes(const ConvArgs& a);   // dZ spectrum shared by backward-weights and backward-data
 int fft_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, uint8_t* argmax, float drop_p,
             uint32_t seed, int layer, float* xspec, void* ws, size_t ws_bytes, hipStream_t st);
 int fft_dgrad(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, const float* x, float inv_keep,
-              const uint8_t* prev_argmax, int prev_pool, void* ws, size_t ws_bytes, hipStream_t st);
+              const uint8_t* prev_argmax, int prev_pool, const float* dzspec, void* ws, size_t ws_bytes, hipStream_t st);
 int fft_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, MPtr2 db, int accumulate,
-              const float* xspec, void* ws, size_t ws_bytes, hipStream_t st);   // also writes the bias gradient
+              const float* xspec, float* dzspec_out, void* ws, size_t ws_bytes, hipStream_t st);   // also writes the bias gradient
 
 // zns_cv1.hip -- direct (HBM-bound) kernels for the cin==1 first layer
 int cv1_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, float drop_p, uint32_t seed,
