@@ -164,11 +164,11 @@ class StackParams:
 
 
 def stack_forward(x: torch.Tensor, P: StackParams, B: int, drop_p: float, seed: int, save: bool,
-                  with_head: bool = True):
+                  with_head: bool = True, ws_slot: int = 0):
     """x: [nbr*B, 1, 96, T] -> (emb [nbr*B, T] or None, acts [y1..y8], argmax {layer: u8})."""
     nbr = P.nbr
     T = x.shape[-1]
-    ws = workspace(conv_workspace_bytes(nbr, B, T), x.device)
+    ws = workspace(conv_workspace_bytes(nbr, B, T), x.device, ws_slot)
     acts: List[torch.Tensor] = []
     argm: Dict[int, torch.Tensor] = {}
     cur = x
@@ -190,7 +190,7 @@ def stack_forward(x: torch.Tensor, P: StackParams, B: int, drop_p: float, seed: 
 def stack_backward(x: torch.Tensor, P: StackParams, B: int, acts: List[torch.Tensor], argm: Dict[int, torch.Tensor],
                    emb: Optional[torch.Tensor], demb: Optional[torch.Tensor], dh: Optional[torch.Tensor],
                    inv_keep: float, G: StackParams, accumulate: bool = False, conv_grads: bool = True,
-                   after_layer=None) -> None:
+                   after_layer=None, ws_slot: int = 0) -> None:
     """Writes parameter gradients into the tensors of G (same structure as P).
 
     demb: grad w.r.t. the embeddings (head fused) -- or dh: grad w.r.t. cv8's RAW output when the head
@@ -199,7 +199,7 @@ def stack_backward(x: torch.Tensor, P: StackParams, B: int, acts: List[torch.Ten
     """
     nbr = P.nbr
     T = x.shape[-1]
-    ws = workspace(conv_workspace_bytes(nbr, B, T), x.device)
+    ws = workspace(conv_workspace_bytes(nbr, B, T), x.device, ws_slot)
     if demb is not None:
         dz = head_bwd(nbr, B, T, acts[7], emb, demb, P.fc_w, inv_keep, G.fc_w, G.fc_b, accumulate, ws)
         if after_layer:
