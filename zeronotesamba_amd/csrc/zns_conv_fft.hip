@@ -144,14 +144,21 @@ constexpr int IVMAX = FN - 12;     // V <= 52 (kw >= 13)
 __device__ __forceinline__ int fastdiv(int x, int d, uint32_t magic) { return d == 1 ? x : (int)__umulhi((uint32_t)x, magic); }
 static uint32_t div_magic(int d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); }
 
-template <int MODE>
+// VW > 1: V and T are multiples of VW (4: cv2, cv4, cv6 at T = 512; 2: cv3, cv5): the epilogue moves VW samples per
+// thread with 8- or 16-byte LDS reads, mask loads and stores; the LDS row stride is then V itself.
+template <int N> struct VecOf;
+template <> struct VecOf<2> { typedef f32x2 type; typedef uint16_t amtype; };
+template <> struct VecOf<4> { typedef f32x4 type; typedef uint32_t amtype; };
+template <> struct VecOf<1> { typedef float type; typedef uint8_t amtype; };
+
+template <int MODE, int VW>
 __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__ S, float* __restrict__ out, int C, int H,
                                                        int T, int V, int NB, int chunks, int WPB, int NS, InvEpi E) {
     extern __shared__ __attribute__((aligned(16))) float stage[];   // [256][VS], VS odd: per-lane rows hit distinct banks
     const int pool = MODE == 1 ? E.pool : 1;
     const int Hq = H / pool;                       // output rows per channel (pooled rows in MODE 1)
     const int CP = C * H * NB;
-    const int VS = V | 1;
+    const int VS = VW > 1 ? V : (V | 1);
     const int chunk = blockIdx.x % chunks;
     const int ns = blockIdx.x / chunks;             // spectral sample = (sample, segment)
     const int n = ns / NS, bseg = (ns - n * NS) * NB;
@@ -185,6 +192,91 @@ __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__
     const int nout = (nwin / pool) * V;
     const int br = n / (MODE == 1 ? E.B : 1), bb = n - br * (MODE == 1 ? E.B : 1);
     const uint32_t lseed = MODE == 1 ? layer_seed(E.seed, E.layer, br) : 0u;
+    if constexpr (VW > 1) {
+        typedef typename VecOf<VW>::type vec_t;
+        typedef typename VecOf<VW>::amtype am_t;
+        const int V4n = V / VW;
+        const int nout4 = (nwin / pool) * V4n;
+        constexpr int EV = 2;                      // 2 x 4 outputs per thread and trip, loads before stores
+        for (int e0 = threadIdx.x; e0 < nout4; e0 += 256 * EV) {
+            vec_t r[EV], mk[EV];
+            uint32_t amw[EV];
+            size_t o[EV];
+            int Rq[EV], col[EV];
+            bool ok[EV];
+#pragma unroll
+            for (int u = 0; u < EV; ++u) {
+                const int e = e0 + u * 256;
+                const int w = fastdiv(e, V4n, E.mV), v = (e - w * V4n) * VW;
+                const int lg = fastdiv(w, NB, E.mNB), b = w - lg * NB;
+                col[u] = (bseg + b) * V + v;
+                ok[u] = e < nout4 && col[u] < T;
+                Rq[u] = Rq0 + lg;
+                o[u] = ((size_t)n * C * Hq + Rq[u]) * T + col[u];
+#pragma unroll
+                for (int k = 0; k < VW; ++k) { r[u][k] = 0.f; mk[u][k] = 1.f; }
+                amw[u] = 0u;
+                if (ok[u]) {
+                    const float* sp = stage + (lg * group + b) * VS + v;
+                    r[u] = *reinterpret_cast<const vec_t*>(sp);
+                    for (int a = 1; a < pool; ++a) {
+                        const vec_t t = *reinterpret_cast<const vec_t*>(sp + a * NB * VS);
+#pragma unroll
+                        for (int k = 0; k < VW; ++k)
+                            if (t[k] > r[u][k]) { r[u][k] = t[k]; amw[u] = (amw[u] & ~(0xffu << (8 * k))) | ((uint32_t)a << (8 * k)); }
+                    }
+                    if (MODE == 1) {
+                        const float bvv = E.bias.p[br][fastdiv(Rq[u], Hq, E.mHq)];
+#pragma unroll
+                        for (int k = 0; k < VW; ++k) mk[u][k] = bvv;
+                    }
+                    if (MODE == 2) {
+                        if (E.xmask) mk[u] = *reinterpret_cast<const vec_t*>(E.xmask + o[u]);
+                        if (E.prev_pool > 1) amw[u] = *reinterpret_cast<const am_t*>(E.prev_argmax + o[u]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < EV; ++u) {
+                if (!ok[u]) continue;
+                vec_t rr = r[u];
+                if (MODE == 0) {
+                    *reinterpret_cast<vec_t*>(out + o[u]) = rr;
+                } else if (MODE == 1) {
+#pragma unroll
+                    for (int k = 0; k < VW; ++k) {
+                        float t = rr[k] + mk[u][k];
+                        t = t > 0.f ? t : 0.f;
+                        if (E.thresh) {
+                            const uint64_t idx = ((uint64_t)bb * C * Hq + Rq[u]) * T + col[u] + k;
+                            t = drop_keep(lseed, idx, E.thresh) ? t * E.inv_keep : 0.f;
+                        }
+                        rr[k] = t;
+                    }
+                    *reinterpret_cast<vec_t*>(out + o[u]) = rr;
+                    if (E.argmax && pool > 1) *reinterpret_cast<am_t*>(E.argmax + o[u]) = (am_t)amw[u];
+                } else {
+                    if (E.xmask) {
+#pragma unroll
+                        for (int k = 0; k < VW; ++k) rr[k] = (mk[u][k] != 0.f) ? rr[k] * E.inv_keep : 0.f;
+                    }
+                    const int pp = E.prev_pool;
+                    if (pp > 1) {
+                        float* d = out + (((size_t)n * C * Hq + Rq[u]) * pp) * T + col[u];
+                        for (int q = 0; q < pp; ++q) {
+                            vec_t t;
+#pragma unroll
+                            for (int k = 0; k < VW; ++k) t[k] = ((int)((amw[u] >> (8 * k)) & 0xffu) == q) ? rr[k] : 0.f;
+                            *reinterpret_cast<vec_t*>(d + (size_t)q * T) = t;
+                        }
+                    } else {
+                        *reinterpret_cast<vec_t*>(out + o[u]) = rr;
+                    }
+                }
+            }
+        }
+        return;
+    }
     // four outputs per thread and trip: their global loads (mask, arg-max, bias) are all in flight before the first
     // store, instead of one exposed memory round trip per element
     constexpr int EU = 4;
@@ -517,12 +609,23 @@ static int run_spec_inv(const float* S, float* out, int nb, int C, int H, int T,
     const int group = pool * g.NB;
     const int WPB = (256 / group) * group;
     const int chunks = ceil_div(C * g.P, WPB);
-    E.mV = div_magic(g.V);
+    auto al = [](const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; };
+    int vw = 1;   // samples per thread in the epilogue: the widest vector V, T and every pointer allow
+    for (int cand : {4, 2})
+        if (vw == 1 && g.V % cand == 0 && T % cand == 0 && al(out, 4 * cand) && al(E.xmask, 4 * cand) && al(E.argmax, cand) &&
+            al(E.prev_argmax, cand))
+            vw = cand;
+    E.mV = div_magic(g.V / vw);
     E.mNB = div_magic(g.NB);
     E.mHq = div_magic(H / pool);
-    const size_t lds = (size_t)256 * (g.V | 1) * sizeof(float);
-    hipLaunchKernelGGL(spec_inv_kernel<MODE>, dim3((unsigned)((size_t)nb * chunks)), dim3(256), lds, st, S, out, C, H, T,
-                       g.V, g.NB, chunks, WPB, g.NS, E);
+    const size_t lds = (size_t)256 * (vw > 1 ? g.V : (g.V | 1)) * sizeof(float);
+    const dim3 grid((unsigned)((size_t)nb * chunks));
+    if (vw == 4)
+        hipLaunchKernelGGL((spec_inv_kernel<MODE, 4>), grid, dim3(256), lds, st, S, out, C, H, T, g.V, g.NB, chunks, WPB, g.NS, E);
+    else if (vw == 2)
+        hipLaunchKernelGGL((spec_inv_kernel<MODE, 2>), grid, dim3(256), lds, st, S, out, C, H, T, g.V, g.NB, chunks, WPB, g.NS, E);
+    else
+        hipLaunchKernelGGL((spec_inv_kernel<MODE, 1>), grid, dim3(256), lds, st, S, out, C, H, T, g.V, g.NB, chunks, WPB, g.NS, E);
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
 }
