@@ -1,0 +1,45 @@
+"""bench.py's output contract (the driver parses this line) and its work accounting."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_work_accounting_matches_the_survey():
+    sys.path.insert(0, ROOT)
+    import bench
+    # 2.035e13 FLOP per step in the direct form (fwd + both backward passes, no cv1 dgrad)
+    assert abs(bench.STEP_FLOP / 2.035e13 - 1) < 2e-3
+    # frequency-domain cv4 forward: 95 useful real GEMM-convs of 128 x (128*9) per window position, 352 positions, 32 samples
+    assert bench.spectral_flop("cv4", True) == 2.0 * 95 * 128 * 128 * 9 * 352 * 32
+    assert bench.spectral_flop("cv4", False) == 2.0 * 96 * 128 * 128 * 9 * 352 * 32
+    assert bench.PROBE["flop"] == bench.spectral_flop("cv4", True)
+    assert 2.5e12 < bench.EXEC_FLOP < 2.7e12
+    assert bench.host_cores() >= 1
+
+
+@pytest.mark.gpu
+def test_bench_line_has_every_contract_field():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["steps"] == 2 and r["warmup"] == 1 and r["higher_is_better"] is True
+    assert r["scaling"] == "weak" and r["vs_baseline"] is None and r["dtype"] == "f32" and r["data"] == "synthetic"
+    assert "workload" in r["config"] and "model" not in r["config"]
+    assert abs(r["value"] - 1000.0 / r["ms_per_step"]) < 1e-6 * r["value"]
+    rf = r["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["launches_timed"] == 2
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.3 < rf["frac"] < 1.0
+    assert 5.0 < r["value"] < 200.0
