@@ -21,6 +21,22 @@ def run(n_clips, iters):
     return {"n_clips": n_clips, "ms": dt * 1e3, "clips_per_s": n_clips / dt, "algorithmic_GBps": alg / dt / 1e9,
             "frac_of_8TBps": alg / dt / 8e12}
 
+def cpu_oracle(n_clips=2):
+    """The numpy restatement of the reference's librosa/resampy path, one process, per-clip loop as the reference does."""
+    import numpy as np
+    from oracle import vqt_ref
+    rng = np.random.default_rng(1234)
+    y = (0.1 * rng.standard_normal((n_clips, 160000))).astype(np.float32)
+    vqt_ref.generate_XQT(y[0], 16000, "vqt")          # builds and caches the filter bank
+    t0 = time.perf_counter()
+    for i in range(n_clips):
+        vqt_ref.generate_XQT(y[i], 16000, "vqt")
+    dt = (time.perf_counter() - t0) / n_clips
+    return {"cpu_oracle_s_per_clip": dt, "cpu_oracle_clips_per_s": 1.0 / dt, "kind": "port (numpy, 1 process)"}
+
+
 if __name__ == "__main__":
     for n, it in ((32, 50), (512, 10), (4096, 3)):
         print(json.dumps(run(n, it)))
+    if "--cpu" in sys.argv:
+        print(json.dumps(cpu_oracle()))
