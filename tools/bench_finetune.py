@@ -13,7 +13,7 @@ from zeronotesamba_amd.models.models import Down_CNN
 from zeronotesamba_amd.optim import Adam
 
 dev = torch.device("cuda", 0)
-T = int(sys.argv[1]) if len(sys.argv) > 1 else 1876
+T = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 1876
 torch.manual_seed(0)
 m = Down_CNN().to(dev)
 opt = Adam(m.parameters(), lr=5e-7)
@@ -41,4 +41,17 @@ for _ in range(K):
     l = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / K
-print(json.dumps({"T": T, "ms_per_step": dt * 1e3, "steps_per_s": 1 / dt, "loss": float(l)}))
+print(json.dumps({"T": T, "ms_per_step": dt * 1e3, "steps_per_s": 1 / dt, "loss": float(l.detach())}))
+
+if "--cpu" in sys.argv:
+    # the CPU oracle (stock torch ops, numerically the reference) on the same step, host cores of this box
+    import bench
+    from oracle import step_ref
+    torch.set_num_threads(bench.host_cores())
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    op = step_ref.OracleParams(sd, 5e-7)
+    vq = torch.stack([x[0, 0, 0].cpu(), x[1, 0, 0].cpu()])
+    step_ref.finetune_step(op, vq[..., :64].contiguous(), msk[0, :64].cpu())      # warm-up
+    t0 = time.perf_counter()
+    step_ref.finetune_step(op, vq, msk[0].cpu())
+    print(json.dumps({"T": T, "cpu_oracle_s_per_step": time.perf_counter() - t0, "cores": bench.host_cores()}))
