@@ -143,6 +143,25 @@ __device__ __forceinline__ void load_slab(const float* wslab, float* lds_slab, i
     for (int q = wid; q < NI; q += C::NW) glds16(wslab + q * 256 + lane * 4, lds_slab + q * 256);
 }
 
+// Epilogue helper: one 32x32 accumulator tile -> global rows of `ld` floats, through a per-wave LDS tile so that every
+// lane writes 16 bytes (four consecutive columns): 4 store instructions per tile instead of 16.  Epilogues run with the
+// matrix pipes idle (one workgroup per CU), so their instruction count is paid in full.  Requirements: ld % 4 == 0,
+// 16-byte aligned base, col0 % 4 == 0; columns >= ncols are skipped.  tb: this wave's 32 x ETS floats of LDS.
+constexpr int ETS = 36;
+__device__ __forceinline__ void store_tile_t(float* tb, const f32x16& acc, float* __restrict__ dst0, size_t ld, int col0,
+                                             int ncols, int lane) {
+    const int lane_j = lane & 31, lane_h = lane >> 5, rr = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tb[acc_row(k, lane_h) * ETS + lane_j] = acc[k];
+    // same-wave LDS traffic is ordered: no barrier between the writes above and the reads below
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = rr + 8 * q;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(tb + row * ETS + c4);
+        if (col0 + c4 < ncols) *reinterpret_cast<f32x4*>(dst0 + (size_t)row * ld + col0 + c4) = v;
+    }
+}
+
 template <class C>
 __device__ __forceinline__ void compute_stage(const float* __restrict__ pa, const float* __restrict__ pb,
                                               f32x16 (&acc)[C::MT][C::RT][C::CT], int dil = 1) {
@@ -280,6 +299,19 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
     if constexpr (C::HET) {
         // tile t of this wave: type A -> (channel tile t, column tile wid); type B -> (channel tile wid-8, column tile 8+t)
         const int pp = A.prev_pool;
+        if (A.xmask == nullptr && pp == 1 && (T & 3) == 0 && (reinterpret_cast<uintptr_t>(A.dx) & 15) == 0) {
+            // plain stores (the frequency-domain use): 16 bytes per lane through store_tile_t
+            __syncthreads();                               // every wave is done with the last stage's operands
+            float* tb = smem + wid * (32 * ETS);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (!type_a && t == 3) break;
+                const int co0 = cob * C::COB + (type_a ? t : het_m0) * 32;
+                store_tile_t(tb, acc[t][0][0], A.dx + ((size_t)n * C::COUT + co0) * T, (size_t)T,
+                             w0 + (type_a ? wid : 8 + t) * 32, T, lane);
+            }
+            return;
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             if (!type_a && t == 3) break;
@@ -344,6 +376,24 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
         }
     } else {
         const int pp = A.prev_pool;
+        if constexpr (C::LDS_BYTES >= C::NW * 32 * ETS * 4) {
+            if (A.xmask == nullptr && pp == 1 && (T & 3) == 0 && (reinterpret_cast<uintptr_t>(A.dx) & 15) == 0) {
+                __syncthreads();                           // every wave is done with the last stage's operands
+                float* tb = smem + wid * (32 * ETS);
+#pragma unroll
+                for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+                    for (int rt = 0; rt < C::RT; ++rt)
+#pragma unroll
+                        for (int ct = 0; ct < C::CT; ++ct) {
+                            const int co0 = cob * C::COB + (wm * C::MT + m) * 32;
+                            const int row = h0 + wr * C::RT + rt;
+                            store_tile_t(tb, acc[m][rt][ct], A.dx + (((size_t)n * C::COUT + co0) * C::H + row) * T,
+                                         (size_t)C::H * T, w0 + (wc * C::CT + ct) * 32, T, lane);
+                        }
+                return;
+            }
+        }
 #pragma unroll
         for (int m = 0; m < C::MT; ++m) {
             const int co0 = cob * C::COB + (wm * C::MT + m) * 32;
@@ -594,6 +644,24 @@ __global__ void __launch_bounds__(C::NT) wgrad_core(WgArgs A) {
 
     // partial slab: [br][ks][q][co][ci]
     float* sl = A.slab + ((size_t)br * A.KS + ks) * C::Q * C::COUT * C::CIN;
+    if constexpr (C::LDS_BYTES >= C::NW * 32 * ETS * 4 && C::CIN % 4 == 0) {
+        if ((reinterpret_cast<uintptr_t>(sl) & 15) == 0) {
+            __syncthreads();                               // every wave is done with the last K-tile's operands
+            float* tb = smem + wid * (32 * ETS);
+#pragma unroll
+            for (int s = 0; s < C::NS; ++s) {
+                const int q = q0 + wq * C::NS + s;
+                if (q >= C::Q) continue;
+#pragma unroll
+                for (int m = 0; m < C::MT; ++m) {
+                    const int co0 = cob * C::COB + (wmw * C::MT + m) * 32;
+                    store_tile_t(tb, acc[m][s], sl + ((size_t)q * C::COUT + co0) * C::CIN, (size_t)C::CIN,
+                                 (cit * C::WCI + wci) * 32, C::CIN, lane);
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int s = 0; s < C::NS; ++s) {
         const int q = q0 + wq * C::NS + s;
