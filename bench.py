@@ -47,12 +47,12 @@ def spectral_flop(layer: str, useful: bool) -> float:
 
 # MFMA FLOP actually executed per step: cv2..cv6 in the frequency domain (3 passes), cv7/cv8 direct (3 passes)
 EXEC_FLOP = 3 * sum(spectral_flop(l, False) for l in LAYER_GEOM) + 3 * 2 * 2 * B * (MACS["cv7"] + MACS["cv8"])
-# dominant kernel (profiles/): the frequency-domain forward GEMM-conv of cv4 (conv_core<256,256,1x9 taps>)
+# dominant kernel (profiles/): the frequency-domain forward GEMM-conv of cv4 (conv_core<128,128,1x9 taps, 12-wave HET layout>)
 PROBE = dict(kind=0, cin=128, cout=128, kh=9, name="conv_core<spectral cv4 forward: 96 real 128x1152 GEMM-convs per sample, 9 row taps>",
              flop=spectral_flop("cv4", True),
-             # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/r01_final_pmc_summary.csv):
-             # FETCH_SIZE 602 449 KB x 2 (gfx950 counts the 128-B requests of 16-byte loads as 64 B) + WRITE_SIZE 540 672 KB
-             traffic=(2 * 602449 + 540672) * 1024.0)
+             # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/r01h_pmc_summary.csv):
+             # FETCH_SIZE 608 304 KB x 2 (gfx950 counts the 128-B requests of 16-byte loads as 64 B) + WRITE_SIZE 540 672 KB
+             traffic=(2 * 608304 + 540672) * 1024.0)
 
 
 def synth_batch(seed: int, device) -> torch.Tensor:
