@@ -10,7 +10,7 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 
 constexpr int SLAB = 9216, PATCH = 4096;   // floats, as FF4
 
-template <int MODE>   // 0: LDS reads only, 1: + barrier per stage, 2: + DMA per stage
+template <int MODE>   // 0: LDS reads only, 1: + barrier per stage, 2: + DMA per stage, 3: 2 + the HET wave mix (8 x 4x1, 4 x 1x3 tiles)
 __global__ void __launch_bounds__(768) k(const float* __restrict__ g, float* out, int stages) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -34,6 +34,20 @@ __global__ void __launch_bounds__(768) k(const float* __restrict__ g, float* out
             float* np = smem + 2 * SLAB + ((st + 1) & 1) * PATCH;
             for (int q = wid; q < PATCH / 256; q += 12)
                 __builtin_amdgcn_global_load_lds((gbl_void_t*)(gb + ((q * 256 + lane * 4) & 4095)), (lds_void_t*)(np + q * 256), 16, 0, 0);
+        }
+        if (MODE == 3 && wid >= 8) {
+#pragma unroll
+            for (int cp = 0; cp < 4; ++cp)
+#pragma unroll
+                for (int s = 0; s < 9; ++s) {
+                    const float a = slab[(cp * 9 + s) * 256 + lane * 4 + (wid - 8)];
+                    float b[3];
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) b[ct] = patch[(2 * cp + (lane >> 5)) * 456 + (8 + ct) * 32 + (lane & 31) + s * 11];
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[ct], acc[ct], 0, 0, 0);
+                }
+            continue;
         }
 #pragma unroll
         for (int cp = 0; cp < 4; ++cp)
@@ -61,7 +75,7 @@ static void run(const float* g, float* out, int stages, int blocks) {
     hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(768), lds, 0, g, out, stages);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    const double flop = (double)blocks * 12 * stages * 36 * 4 * 4096;
+    const double flop = (double)blocks * (MODE == 3 ? 11 : 12) * stages * 36 * 4 * 4096;
     printf("mode %d, %d WGs x %d stages: %.3f ms  %.1f TFLOP/s (%.1f%% of 157.3)  %s\n", MODE, blocks, stages, ms, flop / ms / 1e9,
            flop / ms / 1e9 / 157.3 * 100, hipGetErrorString(hipGetLastError()));
 }
@@ -74,6 +88,8 @@ int main() {
     run<1>(g, out, 16 * 12, 256);
     run<2>(g, out, 16 * 12, 256);
     run<2>(g, out, 16, 3072);          // the real grid: 3072 WGs of 16 stages (12 rounds)
+    run<3>(g, out, 16, 3072);          // ... with the 12-wave heterogeneous layout (44 tiles)
+    run<3>(g, out, 16 * 12, 256);
     run<0>(g, out, 16, 3072);
     return 0;
 }
