@@ -40,13 +40,16 @@ template <int CIN_, int COUT_, int KH_, int KW_, int H_, int MT_, int RT_, int C
 struct ConvCfg {
     static constexpr int DILMAX = DILMAX_;
     static constexpr int HET = HET_;
-    static_assert(!HET || (MT_ == 4 && RT_ == 1 && CT_ == 1 && WM_ == 1 && WR_ == 1 && WC_ == 12 && KH_ == 1 && EPI_ == 1),
-                  "HET layout: 12 waves, 4 channel tiles, 11 column tiles");
+    // HET = number of type-A waves NA (8: 11 column tiles, 12 waves; 4: 7 column tiles, 8 waves).  Waves 0..NA-1 own
+    // (4 channel tiles x column tile w), waves NA..NA+3 own (channel tile w-NA x column tiles NA, NA+1, NA+2).
+    static_assert(!HET || ((HET == 8 || HET == 4) && MT_ == 4 && RT_ == 1 && CT_ == 1 && WM_ == 1 && WR_ == 1 &&
+                           WC_ == HET + 4 && KH_ == 1 && EPI_ == 1),
+                  "HET layout: NA + 4 waves, 4 channel tiles, NA + 3 column tiles");
     static constexpr int CIN = CIN_, COUT = COUT_, KH = KH_, KW = KW_, H = H_;
     static constexpr int MT = MT_, RT = RT_, CT = CT_, WM = WM_, WR = WR_, WC = WC_, CK = CK_;
     static constexpr int POOL = POOL_, EPI = EPI_;
     static constexpr int NW = WM * WR * WC, NT = NW * 64;
-    static constexpr int COB = WM * MT * 32, RB = WR * RT, WB = HET ? 11 * 32 : WC * CT * 32;
+    static constexpr int COB = WM * MT * 32, RB = WR * RT, WB = HET ? (HET + 3) * 32 : WC * CT * 32;
     static constexpr int PH = KH / 2, PW = KW / 2;
     // Patch rows start at a 16-byte aligned image column (w0 - pw rounded down to a multiple of 4) and are a
     // multiple of 4 floats long, so the patch can be staged with 16-byte LDS-DMA whenever T % 4 == 0.
@@ -265,11 +268,11 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) acc[m][rt][ct][k] = 0.f;
 
-    const bool type_a = !C::HET || wid < 8;            // HET: waves 8..11 own one channel tile x column tiles 8..10
-    const int het_m0 = wid - 8;
+    const bool type_a = !C::HET || wid < C::HET;       // HET: the last four waves own one channel tile x 3 column tiles
+    const int het_m0 = wid - C::HET;
     const int pw_al = (pw + 3) & ~3;   // patch origin = tile origin - pw_al (16-byte aligned); reads skip pw_al - pw
     const int abase = C::HET ? lane * 4 + (type_a ? 0 : het_m0) : wm * (64 * C::MT) + lane * C::MT;
-    const int bbase = C::HET ? lane_h * C::PS + (type_a ? wid : 8) * 32 + lane_j + (pw_al - pw)
+    const int bbase = C::HET ? lane_h * C::PS + (type_a ? wid : C::HET) * 32 + lane_j + (pw_al - pw)
                              : lane_h * C::PS + (wr * C::RT) * C::PCW + wc * C::CT * 32 + lane_j + (pw_al - pw);
 
     PatchPlan<C> plan;
@@ -308,7 +311,7 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
                 if (!type_a && t == 3) break;
                 const int co0 = cob * C::COB + (type_a ? t : het_m0) * 32;
                 store_tile_t(tb, acc[t][0][0], A.dx + ((size_t)n * C::COUT + co0) * T, (size_t)T,
-                             w0 + (type_a ? wid : 8 + t) * 32, T, lane);
+                             w0 + (type_a ? wid : C::HET + t) * 32, T, lane);
             }
             return;
         }
@@ -316,7 +319,7 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
         for (int t = 0; t < 4; ++t) {
             if (!type_a && t == 3) break;
             const int co0 = cob * C::COB + (type_a ? t : het_m0) * 32;
-            const int col = w0 + (type_a ? wid : 8 + t) * 32 + lane_j;
+            const int col = w0 + (type_a ? wid : C::HET + t) * 32 + lane_j;
             if (col >= T) continue;
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
