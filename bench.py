@@ -118,9 +118,17 @@ def main():
     from zeronotesamba_amd.distributed import init_from_env
     from zeronotesamba_amd.pretext import PretextTrainer
 
-    rank, world, local = init_from_env("nccl" if args.gpus > 1 else None)
+    # ZNS_BENCH_BACKEND=gloo is a functional dry run of the N > 1 path on a box with fewer GPUs than ranks (ranks then
+    # share devices and gradients travel through the host): never a performance number.
+    backend = os.environ.get("ZNS_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_dev = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local_dev)
+    rank, world, local = init_from_env(backend if args.gpus > 1 else None)
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -186,6 +194,7 @@ def main():
                                    "1x96x512 VQT pairs per GPU, dropout 0.1 on"
                                    + (f"; configs[4]-style DDP over {world} GPUs (16/GPU), RCCL grad all-reduce" if world > 1 else ""),
                        "batch_per_gpu": B, "frames": T, "global_batch": B * world, "parallelism": f"dp{world}",
+                       **({"collective_backend": backend + " (dry run, not a performance number)"} if backend != "nccl" and world > 1 else {}),
                        "audio_seconds_per_s": steps_per_s * B * T * HOP / SR,
                        "direct_conv_tflop_per_step": STEP_FLOP / 1e12,
                        "direct_conv_equivalent_tflops_per_gpu": STEP_FLOP * K / dt / 1e12,

@@ -43,3 +43,29 @@ def test_bench_line_has_every_contract_field():
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["launches_timed"] == 2
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.3 < rf["frac"] < 1.0
     assert 5.0 < r["value"] < 200.0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_dry_run_on_one_gpu():
+    """The N > 1 path of bench.py exactly as the driver launches it (torch.distributed.run, one process per rank,
+    rendezvous on 127.0.0.1), with the collective backend switched to gloo so that two ranks can share this box's one
+    GPU: process group, bucketed gradient all-reduce inside the step, barrier-bracketed timing, max over ranks, one
+    JSON line from rank 0 with the whole-job value."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, ZNS_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["scaling"] == "weak"
+    assert r["config"]["global_batch"] == 32 and r["config"]["parallelism"] == "dp2"
+    assert "cpu_baseline" not in r
+    assert abs(r["value"] - 2 * 1000.0 / r["ms_per_step"]) < 1e-6 * r["value"]      # whole-job steps/s
