@@ -28,16 +28,16 @@ using F3 = ConvCfg<64, 128, 5, 15, 32, 4, 2, 1, 1, 2, 4, 4, 1, 0>;
 using F4 = ConvCfg<128, 128, 9, 17, 32, 2, 4, 1, 2, 1, 4, 4, 4, 0>;
 using F5 = ConvCfg<128, 256, 3, 19, 8, 4, 2, 1, 2, 2, 2, 2, 1, 0>;
 using F6 = ConvCfg<256, 256, 5, 21, 8, 1, 8, 1, 8, 1, 1, 2, 8, 0>;
-using F7 = ConvCfg<256, 128, 1, 23, 1, 2, 1, 1, 2, 1, 2, 4, 1, 0>;
-using F8 = ConvCfg<128, 128, 1, 25, 1, 2, 1, 1, 2, 1, 2, 4, 1, 0>;
+using F7 = ConvCfg<256, 128, 1, 23, 1, 1, 1, 1, 4, 1, 2, 4, 1, 0>;
+using F8 = ConvCfg<128, 128, 1, 25, 1, 1, 1, 1, 4, 1, 2, 4, 1, 0>;
 // backward-data: core CIN = conv cout, core COUT = conv cin
 using D2 = ConvCfg<64, 64, 7, 13, 96, 2, 3, 1, 1, 2, 4, 4, 1, 1>;
 using D3 = ConvCfg<128, 64, 5, 15, 32, 2, 4, 1, 1, 2, 4, 4, 1, 1>;
 using D4 = ConvCfg<128, 128, 9, 17, 32, 2, 4, 1, 2, 1, 4, 4, 1, 1>;
 using D5 = ConvCfg<256, 128, 3, 19, 8, 4, 2, 1, 1, 4, 2, 4, 1, 1>;
 using D6 = ConvCfg<256, 256, 5, 21, 8, 4, 2, 1, 2, 4, 1, 2, 1, 1>;
-using D7 = ConvCfg<128, 256, 1, 23, 1, 4, 1, 1, 2, 1, 2, 2, 1, 1>;
-using D8 = ConvCfg<128, 128, 1, 25, 1, 2, 1, 1, 2, 1, 2, 4, 1, 1>;
+using D7 = ConvCfg<128, 256, 1, 23, 1, 2, 1, 1, 4, 1, 2, 2, 1, 1>;
+using D8 = ConvCfg<128, 128, 1, 25, 1, 1, 1, 1, 4, 1, 2, 4, 1, 1>;
 //                CIN COUT KH KW  H  MT NS WMW WQ R
 using W2 = WgCfg<64, 64, 7, 13, 96, 2, 4, 1, 8, 1>;
 using W3 = WgCfg<64, 128, 5, 15, 32, 2, 4, 2, 4, 1>;
