@@ -3,7 +3,7 @@ import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__
 import bench
 from zeronotesamba_amd.pretext import PretextTrainer
 dev = torch.device("cuda", 0)
-tr = PretextTrainer(bench.build_model(dev), batch_len=16, lr=1e-4, seed=5)
+tr = PretextTrainer(bench.build_model(dev), batch_len=16, lr=float(sys.argv[1]) if len(sys.argv) > 1 else 1e-6, seed=5)
 xs = [tr.stack_inputs(bench.synth_batch(i, dev)) for i in range(4)]
 torch.cuda.reset_peak_memory_stats()
 losses = []
