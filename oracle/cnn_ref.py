@@ -87,18 +87,48 @@ def cnn_forward(
     n_branch_batch_offset: int = 0,
     keep: Optional[List[torch.Tensor]] = None,
     taps: Optional[list] = None,
+    replay: Optional[Dict[int, Tuple[torch.Tensor, Optional[torch.Tensor]]]] = None,
+    replay_scale: float = 1.0,
+    flips: Optional[Dict[int, Tuple[int, int, int]]] = None,
 ) -> torch.Tensor:
     """_CNN.forward (models.py:32-74).  x: [B,1,96,T] -> [B,128,T].
 
     drop_seed=None -> eval mode (dropout is the identity, models.py:30 + nn.Module.eval()).
     Otherwise each layer's keep mask is dropout_ref.keep_mask(layer_seed(seed, layer, branch), ...)
     over the layer OUTPUT tensor [B,C,Hp,T] (contiguous linear index).
+
+    replay (mask-replay mode): {layer index: (nonzero mask of the layer output [B,C,Hp,T] bool,
+    arg-max row 0..pool-1 per pooled output uint8 or None)} recorded from ANOTHER implementation's run.
+    The discontinuous decisions of the stack -- which row a max-pool window picks, which elements
+    ReLU/dropout zero -- are then taken from the record instead of being re-derived from this run's
+    values: out = gather(conv, argmax) * mask * replay_scale.  Everything continuous (conv2d and the
+    gradients autograd derives from it) is still stock torch.  Two fp32 implementations resolve
+    near-ties (gap below summation noise) differently; replaying the decisions removes exactly that
+    difference, so per-parameter gradients can be compared at 1e-4 instead of a flip-tolerant 1e-2.
+    flips[li] = (pool windows whose own arg-max differs, mask elements whose own ReLU decision
+    differs, elements) counts how many decisions were actually overridden.
     """
     out = x
     for li, (name, cin, cout, kh, kw, pool) in enumerate(LAYERS):
         w = sd[f"{prefix}pretrained.{name}.weight"]
         b = sd[f"{prefix}pretrained.{name}.bias"]
         out = F.conv2d(out, w, b, padding=(kh // 2, kw // 2))
+        if replay is not None:
+            mask, am = replay[li]
+            n_am = 0
+            if pool > 1:
+                Bn, C, Hh, Tt = out.shape
+                z5 = out.reshape(Bn, C, Hh // pool, pool, Tt)
+                own = z5.detach().argmax(dim=3)   # first maximum wins, as max_pool2d
+                n_am = int((own != am.long()).sum())
+                out = torch.gather(z5, 3, am.long().unsqueeze(3)).squeeze(3)
+            n_mask = int(((out.detach() > 0) != mask).sum()) if replay_scale == 1.0 else -1
+            if flips is not None:
+                flips[li] = (n_am, n_mask, mask.numel())
+            out = out * mask.to(out.dtype) * replay_scale
+            if taps is not None:
+                taps.append(out)
+            continue
         if pool > 1:
             out = F.max_pool2d(out, (pool, 1))
         out = F.relu(out)
@@ -112,24 +142,32 @@ def cnn_forward(
     return torch.squeeze(out, dim=2)
 
 
-def ds_cnn_forward(sd, prefix, x, drop_seed=None, branch=0, taps=None) -> torch.Tensor:
+def ds_cnn_forward(sd, prefix, x, drop_seed=None, branch=0, taps=None, replay=None, replay_scale=1.0,
+                   flips=None) -> torch.Tensor:
     """DS_CNN.forward (models.py:91-103). -> [B, T]"""
-    h = cnn_forward(sd, prefix, x, drop_seed=drop_seed, branch=branch, taps=taps)
+    h = cnn_forward(sd, prefix, x, drop_seed=drop_seed, branch=branch, taps=taps, replay=replay,
+                    replay_scale=replay_scale, flips=flips)
     y = F.conv1d(h, sd[f"{prefix}fc1.weight"], sd[f"{prefix}fc1.bias"])
     y = torch.sigmoid(y)
     return y.reshape(y.size(0), y.size(1) * y.size(2))
 
 
-def pretext_forward(sd, anc, pos, drop_seed=None, prefix=""):
-    """Pretext_CNN.forward (models.py:117-124)."""
-    a = ds_cnn_forward(sd, f"{prefix}anchor.", anc, drop_seed=drop_seed, branch=0)
-    p = ds_cnn_forward(sd, f"{prefix}postve.", pos, drop_seed=drop_seed, branch=1)
+def pretext_forward(sd, anc, pos, drop_seed=None, prefix="", replay=None, replay_scale=1.0, flips=None):
+    """Pretext_CNN.forward (models.py:117-124).  replay: {"anchor": {...}, "postve": {...}} (see cnn_forward)."""
+    fa = fp = None
+    if flips is not None:
+        fa, fp = flips.setdefault("anchor", {}), flips.setdefault("postve", {})
+    a = ds_cnn_forward(sd, f"{prefix}anchor.", anc, drop_seed=drop_seed, branch=0,
+                       replay=None if replay is None else replay["anchor"], replay_scale=replay_scale, flips=fa)
+    p = ds_cnn_forward(sd, f"{prefix}postve.", pos, drop_seed=drop_seed, branch=1,
+                       replay=None if replay is None else replay["postve"], replay_scale=replay_scale, flips=fp)
     return a, p
 
 
-def down_forward(sd, anc, pos, reduction="max", drop_seed=None):
+def down_forward(sd, anc, pos, reduction="max", drop_seed=None, replay=None, replay_scale=1.0, flips=None):
     """Down_CNN.forward (models.py:138-150); sd keys carry the 'pretext.' prefix."""
-    a, p = pretext_forward(sd, anc, pos, drop_seed=drop_seed, prefix="pretext.")
+    a, p = pretext_forward(sd, anc, pos, drop_seed=drop_seed, prefix="pretext.", replay=replay,
+                           replay_scale=replay_scale, flips=flips)
     if reduction == "mean":
         return torch.div(a + p, 2)
     return torch.maximum(a, p)

@@ -3,6 +3,8 @@
 pretext_step  restates /root/reference/zeroNoteSamba/pretext.py:475-492
               (slice batch[:,0:1] / batch[:,1:2], zero_grad, forward, NT-Xent,
               backward, torch.optim.Adam.step with lr=1e-6, :202).
+clmr_step     restates pretext.py:494-511 (pt_task "clmr": ONE shared DS_CNN applied to both
+              views, Adam lr=1e-5, :205-208); sd keys are a lone DS_CNN's (`pretrained.cv1.weight` ...).
 finetune_step restates /root/reference/zeroNoteSamba/epochs.py:48-63
               (Down_CNN forward, BCELoss (loader.py:16), backward, Adam).
 adam_numpy    restates torch.optim.Adam (betas .9/.999, eps 1e-8, no weight decay,
@@ -33,12 +35,38 @@ class OracleParams:
 
 
 def pretext_step(op: OracleParams, batch: torch.Tensor, batch_len: int, tau: float,
-                 drop_seed: Optional[int] = None, step_opt: bool = True):
-    """batch: [B,2,96,T].  Returns (loss, pos, neg, anc_emb, pos_emb)."""
+                 drop_seed: Optional[int] = None, step_opt: bool = True, replay=None, replay_scale: float = 1.0,
+                 flips=None):
+    """batch: [B,2,96,T].  Returns (loss, pos, neg, anc_emb, pos_emb).
+
+    replay / replay_scale / flips: mask-replay mode, see cnn_ref.cnn_forward -- the max-pool and ReLU/dropout
+    decisions are taken from a record of another implementation's run (replay_scale = 1/(1-p) when that run
+    had dropout on, the record's masks then already contain the keep decisions)."""
     anchors = batch[:, 0:1, :, :]
     postves = batch[:, 1:2, :, :]
     op.opt.zero_grad()
-    a, p = cnn_ref.pretext_forward(op.sd, anchors, postves, drop_seed=drop_seed)
+    a, p = cnn_ref.pretext_forward(op.sd, anchors, postves, drop_seed=drop_seed, replay=replay,
+                                   replay_scale=replay_scale, flips=flips)
+    loss, cpos, cneg = ntxent_ref.ntxent(a, p, batch_len, tau)
+    loss.backward()
+    if step_opt:
+        op.opt.step()
+    return float(loss.item()), cpos, cneg, a.detach(), p.detach()
+
+
+def clmr_step(op: OracleParams, batch: torch.Tensor, batch_len: int, tau: float,
+              drop_seed: Optional[int] = None, step_opt: bool = True, replay=None, replay_scale: float = 1.0,
+              flips=None):
+    """batch: [B,2,96,T].  anc_emb = model(anchors); pos_emb = model(postves) with the SAME weights (pretext.py:501-502).
+    Returns (loss, pos, neg, anc_emb, pos_emb).  replay: {"anchor": {...}, "postve": {...}} decisions of the two passes."""
+    op.opt.zero_grad()
+    fa = fp = None
+    if flips is not None:
+        fa, fp = flips.setdefault("anchor", {}), flips.setdefault("postve", {})
+    a = cnn_ref.ds_cnn_forward(op.sd, "", batch[:, 0:1, :, :], drop_seed=drop_seed, branch=0,
+                               replay=None if replay is None else replay["anchor"], replay_scale=replay_scale, flips=fa)
+    p = cnn_ref.ds_cnn_forward(op.sd, "", batch[:, 1:2, :, :], drop_seed=drop_seed, branch=0,
+                               replay=None if replay is None else replay["postve"], replay_scale=replay_scale, flips=fp)
     loss, cpos, cneg = ntxent_ref.ntxent(a, p, batch_len, tau)
     loss.backward()
     if step_opt:
@@ -47,13 +75,15 @@ def pretext_step(op: OracleParams, batch: torch.Tensor, batch_len: int, tau: flo
 
 
 def finetune_step(op: OracleParams, vqt: torch.Tensor, msk: torch.Tensor, reduction: str = "max",
-                  drop_seed: Optional[int] = None, step_opt: bool = True):
+                  drop_seed: Optional[int] = None, step_opt: bool = True, replay=None, replay_scale: float = 1.0,
+                  flips=None):
     """vqt: [2,96,T], msk: [T] in {0,0.5,1} (ballroom.py:219-221).  sd keys prefixed 'pretext.'."""
     v1 = vqt[0].reshape(1, 1, vqt.shape[1], vqt.shape[2])
     v2 = vqt[1].reshape(1, 1, vqt.shape[1], vqt.shape[2])
     m = msk.reshape(1, -1)
     op.opt.zero_grad()
-    out = cnn_ref.down_forward(op.sd, v1, v2, reduction=reduction, drop_seed=drop_seed)
+    out = cnn_ref.down_forward(op.sd, v1, v2, reduction=reduction, drop_seed=drop_seed, replay=replay,
+                               replay_scale=replay_scale, flips=flips)
     loss = F.binary_cross_entropy(out, m)
     loss.backward()
     if step_opt:

@@ -102,6 +102,67 @@ def resample2(y: np.ndarray) -> np.ndarray:
     return acc.astype(np.float32)
 
 
+def resample_general(x: np.ndarray, sr_orig: float, sr_new: float) -> np.ndarray:
+    """resampy 0.4.2 `core.resample(x, sr_orig, sr_new, filter="kaiser_fast")` for 1-D float32 x, restated in its
+    GENERAL form (any ratio): core.py computes
+        sample_ratio = sr_new / sr_orig;  n_out = int(len(x) * sample_ratio);  y = zeros(n_out, dtype=x.dtype)
+        interp_win = half window (x sample_ratio when downsampling);  interp_delta = diff(interp_win, append=last)
+        scale = min(1, sample_ratio);  t_out = arange(n_out) / sample_ratio
+    and interpn.py::_resample_loop walks, per output sample, the left wing (x[n], x[n-1], ...) and then the right wing
+    (x[n+1], ...) of the windowed sinc with linear interpolation between table entries
+        weight = interp_win[offset + i*index_step] + eta * interp_delta[offset + i*index_step],   y[t] += weight * x[...]
+    where y is float32: every partial sum is rounded to float32.  Scalar loops, literal order: slow, small inputs only.
+    `resample2` above is this loop specialised by hand to the exact 2:1 ratio (frac = 0, eta = 0); tests/test_vqt.py
+    asserts the two agree bit for bit, so the specialisation is not taken on trust."""
+    x = np.asarray(x, dtype=np.float32)
+    sample_ratio = float(sr_new) / float(sr_orig)
+    n_out = int(x.shape[0] * sample_ratio)
+    y = np.zeros(n_out, dtype=np.float32)
+    interp_win = kaiser_fast_half_window().astype(np.float64).copy()
+    num_table = 2 ** KF_PREC
+    if sample_ratio < 1:
+        interp_win *= sample_ratio
+    interp_delta = np.diff(interp_win, append=interp_win[-1])
+    scale = min(1.0, sample_ratio)
+    t_out = np.arange(n_out) * (1.0 / sample_ratio)
+    index_step = int(scale * num_table)
+    nwin = interp_win.shape[0]
+    n_orig = x.shape[0]
+    for t in range(n_out):
+        time_register = t_out[t]
+        n = int(time_register)
+        frac = scale * (time_register - n)
+        index_frac = frac * num_table
+        offset = int(index_frac)
+        eta = index_frac - offset
+        i_max = min(n + 1, (nwin - offset) // index_step)
+        for i in range(i_max):
+            weight = interp_win[offset + i * index_step] + eta * interp_delta[offset + i * index_step]
+            y[t] = np.float32(np.float64(y[t]) + weight * np.float64(x[n - i]))
+        frac = scale - frac
+        index_frac = frac * num_table
+        offset = int(index_frac)
+        eta = index_frac - offset
+        k_max = min(n_orig - n - 1, (nwin - offset) // index_step)
+        for k in range(k_max):
+            weight = interp_win[offset + k * index_step] + eta * interp_delta[offset + k * index_step]
+            y[t] = np.float32(np.float64(y[t]) + weight * np.float64(x[n + k + 1]))
+    return y
+
+
+def librosa_resample_general(y: np.ndarray, sr_orig: float, sr_new: float) -> np.ndarray:
+    """librosa 0.8.1 core/audio.py::resample(y, orig_sr, target_sr, res_type="kaiser_fast", fix=True, scale=True):
+    resampy, then util.fix_length to ceil(n * ratio) (zero padded), then `y_hat /= np.sqrt(ratio)` in float32."""
+    ratio = float(sr_new) / float(sr_orig)
+    out = resample_general(y, sr_orig, sr_new)
+    n_fix = int(np.ceil(len(y) * ratio))
+    if n_fix > len(out):
+        out = np.concatenate([out, np.zeros(n_fix - len(out), dtype=np.float32)])
+    out = out[:n_fix].copy()
+    out /= np.float32(np.sqrt(ratio))
+    return out.astype(np.float32)
+
+
 # ------------------------------------------------------------------ filter bank
 def cq_lengths(sr: float, fmin: float, n_bins: int, gamma: float) -> np.ndarray:
     """filters.constant_q_lengths."""
@@ -250,3 +311,73 @@ def xqt_time_domain(y: np.ndarray, mode: str = "vqt") -> np.ndarray:
         k0 = N_BINS - BPO * (i + 1)
         V[k0:k0 + BPO, :nf] = gk @ ypad[idx]
     return V
+
+
+# ------------------------------------------------------------------ independent derivation: brute-force correlator
+def brute_force_response(y: np.ndarray, mode: str = "vqt", octaves=range(N_OCT)) -> Dict[int, np.ndarray]:
+    """A second, FFT-free derivation of each octave's response straight from the `filters.constant_q` definition.
+
+    librosa forms  R[k,t] = sum_{f=0}^{N/2} FFT(b_k)[f] * D[f,t],  D[f,t] = sum_n ypad[t*hop+n] e^{-2 pi i f n / N}
+    (the basis spectrum is NOT conjugated).  Summed over ALL N frequencies this is, by orthogonality of the DFT
+    exponentials, the plain time-domain sum
+        R_full[k,t] = N * sum_n b_k[(-n) mod N] * ypad[t*hop + n]
+    which needs no FFT, no sparsification and no folding.  What librosa computes differs from it only by (1) the
+    negative-frequency half of FFT(b_k) it never forms (b_k is a windowed e^{+i w n}: nearly analytic) and (2) the
+    entries sparsify_rows(1 %) zeroes; both are bounded per (k,t) by `brute_force_bound`.  Returns {octave: complex128
+    [12, frames]} INCLUDING the sqrt(2^i) rescale and the final 1/sqrt(length), i.e. comparable to rows of xqt_complex."""
+    y = np.asarray(y, dtype=np.float32)
+    g = gamma_for(mode)
+    freqs_top = FMIN * (2.0 ** (np.arange(N_BINS, dtype=float) / BPO))[-BPO:]
+    fmin_t = float(np.min(freqs_top))
+    full_lengths = cq_lengths(SR, FMIN, N_BINS, g)
+    out: Dict[int, np.ndarray] = {}
+    my_y = y
+    n_frames = 1 + len(y) // HOP
+    for i in range(N_OCT):
+        if i > 0:
+            my_y = resample2(my_y)
+        if i not in octaves:
+            continue
+        basis, lengths = octave_filters(SR / 2.0 ** i, fmin_t * 2.0 ** -i, g)
+        N = basis.shape[1]
+        b = (basis * (lengths[:, None] / float(N))).astype(np.complex64).astype(np.complex128)
+        hop = HOP // (2 ** i)
+        ypad = np.pad(my_y.astype(np.float64), N // 2, mode="reflect")
+        nf = min(n_frames, 1 + (len(ypad) - N) // hop)
+        rev = b[:, (-np.arange(N)) % N]                       # b_k[(-n) mod N]
+        R = np.zeros((BPO, nf), dtype=np.complex128)
+        for t in range(nf):                                   # plain correlation, frame by frame
+            R[:, t] = N * (rev @ ypad[t * hop:t * hop + N])
+        k0 = N_BINS - BPO * (i + 1)
+        out[i] = R * np.sqrt(2.0 ** i) / np.sqrt(full_lengths[k0:k0 + BPO])[:, None]
+    return out
+
+
+def brute_force_bound(y: np.ndarray, mode: str, i: int) -> np.ndarray:
+    """Per (k,t) bound on |librosa response - brute_force_response| for octave i:
+         ( L1 mass of the dropped positive-frequency entries  +  L1 mass of the negative-frequency half ) * max_f |D[f,t]|
+    scaled like the responses.  [12, frames]."""
+    y = np.asarray(y, dtype=np.float32)
+    g = gamma_for(mode)
+    bank, full_lengths = filter_bank(mode)
+    freqs_top = FMIN * (2.0 ** (np.arange(N_BINS, dtype=float) / BPO))[-BPO:]
+    fmin_t = float(np.min(freqs_top))
+    my_y = y
+    for _ in range(i):
+        my_y = resample2(my_y)
+    basis, lengths = octave_filters(SR / 2.0 ** i, fmin_t * 2.0 ** -i, g)
+    N = basis.shape[1]
+    b = (basis * (lengths[:, None] / float(N))).astype(np.complex64).astype(np.complex128)
+    F = np.fft.fft(b, axis=1)
+    kept = bank[i]["fft_basis"].astype(np.complex128) / np.sqrt(2.0 ** i)
+    dropped = np.abs(F[:, :N // 2 + 1] - kept).sum(axis=1)
+    negative = np.abs(F[:, N // 2 + 1:]).sum(axis=1)
+    hop = HOP // (2 ** i)
+    ypad = np.pad(my_y.astype(np.float64), N // 2, mode="reflect")
+    n_frames = 1 + len(y) // HOP
+    nf = min(n_frames, 1 + (len(ypad) - N) // hop)
+    idx = np.arange(N)[:, None] + hop * np.arange(nf)[None, :]
+    Dmax = np.abs(np.fft.fft(ypad[idx], axis=0)).max(axis=0)
+    k0 = N_BINS - BPO * (i + 1)
+    scale = np.sqrt(2.0 ** i) / np.sqrt(full_lengths[k0:k0 + BPO])
+    return (dropped + negative)[:, None] * Dmax[None, :] * scale[:, None]

@@ -15,6 +15,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def host_threads(cap: int = 16) -> int:
+    """Threads the CPU oracle may use: min(affinity, cgroup CPU quota, cap).  The GPU box's container is quota-limited
+    (16 of 128 cores); more threads than the quota is many times slower."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):

@@ -14,6 +14,8 @@ Cases
   cnn_eval.npz   Pretext_CNN / Down_CNN eval-mode forward, per-layer taps  (models.py)
   step_eval.npz  one + three pretext steps (pretext.py:475-492, dropout off), grads + Adam
   finetune.npz   Down_CNN + BCELoss + Adam step (epochs.py:48-63), max and mean reductions
+  clmr_eval.npz  the "clmr" pretext task (pretext.py:494-511, 567-583): ONE shared DS_CNN on both views,
+                 Adam lr 1e-5 (pretext.py:208); three steps, grads + Adam, and the eval-mode loss triple
   manifest.npz   state-dict keys and shapes
 """
 import os
@@ -27,7 +29,7 @@ sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
 sys.path.insert(0, "/root/reference")
 
 from zeroNoteSamba.models.loss_functions import NTXent  # noqa: E402
-from zeroNoteSamba.models.models import Down_CNN, Pretext_CNN  # noqa: E402
+from zeroNoteSamba.models.models import DS_CNN, Down_CNN, Pretext_CNN  # noqa: E402
 
 from oracle import cnn_ref, dropout_ref  # noqa: E402
 
@@ -168,6 +170,49 @@ def make_step_eval():
     np.savez(os.path.join(HERE, "step_eval.npz"), **out)
 
 
+def make_clmr():
+    """pretext.py:205-208 (DS_CNN, Adam lr=1e-5) driven by the clmr branch of train_epoch (:494-511): anc_emb =
+    model(anchors); pos_emb = model(postves); NTXent; backward; step.  Dropout off (eval): there is no BatchNorm."""
+    B, T, tau, lr = 4, 64, 0.25, 1e-5
+    seed, gain = 9, 2.0
+    out = {"B": B, "T": T, "seed": seed, "gain": gain, "tau": tau, "lr": lr}
+    sd = {k[len("anchor."):]: v for k, v in cnn_ref.synth_state_dict(seed, gain).items() if k.startswith("anchor.")}
+    m = DS_CNN()
+    m.load_state_dict(sd)
+    m.eval()
+    crit = NTXent(B, tau)
+    opt = torch.optim.Adam(m.parameters(), lr=lr)
+    losses = []
+    for it in range(3):
+        batch = cnn_ref.synth_vqt(210 + it, (B, 2, 96, T))
+        anchors = batch[:, 0:1, :, :]
+        postves = batch[:, 1:2, :, :]
+        opt.zero_grad()
+        anc_emb = m(anchors)
+        pos_emb = m(postves)
+        loss, cp, cn = crit(anc_emb, pos_emb)
+        loss.backward()
+        if it == 0:
+            grad_record(m, out, "s0_")
+            out["s0_anc_emb"] = anc_emb.detach().numpy()
+            out["s0_pos_emb"] = pos_emb.detach().numpy()
+        opt.step()
+        losses.append([loss.item(), cp, cn])
+        if it in (0, 2):
+            param_record(m, out, f"s{it}_")
+    out["losses"] = np.array(losses)
+    # val_epoch's clmr branch (:567-583) on the UPDATED weights, two batches: the returned means
+    vals = []
+    with torch.no_grad():
+        for it in range(2):
+            batch = cnn_ref.synth_vqt(220 + it, (B, 2, 96, T))
+            loss, cp, cn = crit(m(batch[:, 0:1, :, :]), m(batch[:, 1:2, :, :]))
+            vals.append([loss.item(), cp, cn])
+    out["val_after"] = np.array(vals)
+    print("clmr", losses, vals)
+    np.savez(os.path.join(HERE, "clmr_eval.npz"), **out)
+
+
 def make_finetune():
     T = 96
     seed, gain = 7, 2.0
@@ -220,4 +265,5 @@ if __name__ == "__main__":
     make_ntxent()
     make_cnn_eval()
     make_step_eval()
+    make_clmr()
     make_finetune()

@@ -195,6 +195,70 @@ def test_finetune_step_golden(golden):
             check_stats(v, g[f"{red}_s0_param_{k}_stats"], g[f"{red}_s0_param_{k}_samples"], rtol=1e-5)
 
 
+@pytest.mark.parametrize("train", [False, True])
+def test_pretext_step_gradients_with_replayed_decisions(train):
+    """Every parameter gradient of one pretext step (pretext.py:475-492) against the CPU oracle at 1e-4 of its L2 norm,
+    with the device's max-pool / ReLU(/dropout) decisions replayed in the oracle (tests/replay_util.py), in eval mode
+    and in train mode (dropout 0.1 on, keep decisions are part of the replayed masks).  The oracle on its own decisions
+    equals the real reference's gradients (tests/test_oracle.py, golden step_eval.npz)."""
+    from replay_util import device_decisions, flip_summary, rel_l2
+    from zeronotesamba_amd.pretext import PretextTrainer
+    from zeronotesamba_amd.models.models import Pretext_CNN
+    B, T, tau = 4, 64, 0.25
+    sd = cnn_ref.synth_state_dict(5, 2.0)
+    m = Pretext_CNN()
+    m.load_state_dict(sd)
+    tr = PretextTrainer(m.to(DEV), batch_len=B, temperature=tau, lr=1e-6, seed=11, train=train)
+    batch = cnn_ref.synth_vqt(200, (B, 2, 96, T))
+    x = tr.stack_inputs(batch)
+    seed = tr._next_seed()
+    out3 = tr.step(x, update=False).tolist()
+    drop_p = 0.1 if train else 0.0
+    replay, emb = device_decisions(x, tr.P, B, drop_p, seed)
+    op = step_ref.OracleParams(sd, 1e-6)
+    flips = {}
+    loss, cp, cn, ra, rp = step_ref.pretext_step(op, batch, B, tau, step_opt=False, replay=replay,
+                                                 replay_scale=1.0 / (1.0 - drop_p), flips=flips)
+    print("decisions overridden:", flip_summary(flips))
+    assert abs(out3[0] - loss) < 2e-5 and abs(out3[1] - cp) < 2e-5 and abs(out3[2] - cn) < 2e-5
+    assert (emb.cpu() - torch.cat([ra, rp])).abs().max().item() < 1e-4
+    ref = op.grads()
+    for k, v in m.named_parameters():
+        assert rel_l2(v.grad, ref[k]) <= 1e-4, (k, rel_l2(v.grad, ref[k]))
+
+
+@pytest.mark.parametrize("red", ["max", "mean"])
+def test_finetune_step_gradients_with_replayed_decisions(red):
+    """epochs.py:48-63 (Down_CNN + BCELoss, batch of one): gradients at 1e-4 with replayed decisions, T = 96 and 313."""
+    from replay_util import device_decisions, rel_l2
+    from zeronotesamba_amd import _ops
+    from zeronotesamba_amd.epochs import bce_loss
+    from zeronotesamba_amd.models.models import Down_CNN
+    for T in (96, 313):
+        vqt = cnn_ref.synth_vqt(300 + T, (2, 96, T))
+        msk = torch.zeros(T)
+        msk[5::31] = 1.0
+        msk[4::31] = 0.5
+        msk[6::31] = 0.5
+        sd = cnn_ref.synth_state_dict(7, 2.0)
+        d = Down_CNN(reduction=red)
+        d.pretext.load_state_dict(sd)
+        d.to(DEV).eval()
+        v1, v2 = vqt[0].reshape(1, 1, 96, T).to(DEV), vqt[1].reshape(1, 1, 96, T).to(DEV)
+        o = d(v1, v2)
+        loss = bce_loss(o, msk.reshape(1, T).to(DEV))
+        loss.backward()
+        P = _ops.StackParams.from_flat(d.pretext.anchor.stack_params() + d.pretext.postve.stack_params(), 2)
+        replay, _ = device_decisions(torch.cat([v1, v2]), P, 1)
+        op = step_ref.OracleParams({"pretext." + k: v for k, v in sd.items()}, 5e-7)
+        rl, ro = step_ref.finetune_step(op, vqt, msk, reduction=red, step_opt=False, replay=replay)
+        assert abs(loss.item() - rl) < 2e-5
+        assert (o.detach().cpu() - ro).abs().max().item() < 1e-4
+        ref = op.grads()
+        for k, v in d.named_parameters():
+            assert rel_l2(v.grad, ref[k]) <= 1e-4, (T, k, rel_l2(v.grad, ref[k]))
+
+
 def test_frozen_backbone_gets_no_conv_grads():
     """loader.py:30-34: requires_grad=False on *.pretrained -> only fc1 receives gradients."""
     from zeronotesamba_amd.models.models import Down_CNN

@@ -186,6 +186,115 @@ def test_clmr_trainer_matches_two_pass_module_path():
         PretextTrainer(Pretext_CNN().to(DEV), pt_task="clmr")
 
 
+def _check_stats(t, stats, samples, rtol, srtol=3e-3, atol=1e-7):
+    f = t.detach().cpu().double().flatten()
+    idx = np.unique(np.linspace(0, f.numel() - 1, 16).astype(np.int64))
+    l2 = max(stats[1], 1e-30)
+    assert abs((f * f).sum().sqrt().item() - stats[1]) <= rtol * l2 + atol
+    assert abs(f.sum().item() - stats[0]) <= rtol * l2 * np.sqrt(f.numel()) + atol
+    np.testing.assert_allclose(f[idx].numpy(), samples, rtol=srtol, atol=srtol * l2 / np.sqrt(f.numel()) + atol)
+
+
+def test_epoch_returns_match_the_reference(golden):
+    """pretext.train_epoch / val_epoch RETURN VALUES against vectors from the real reference (golden step_eval.npz):
+    val_epoch on the first golden batch returns that batch's (loss, pos, neg); train_epoch over the three golden batches
+    (dropout probability set to 0 on the modules' own `dp`, as the fixture was captured in eval mode: there is no
+    BatchNorm, so train and eval differ only by dropout) returns the mean of the three per-step triples, with a stock
+    torch Adam, with the fused Adam, and through PretextTrainer.train_epoch.  pretext.py:453-592."""
+    from zeronotesamba_amd.models.loss_functions import NTXent
+    from zeronotesamba_amd.optim import Adam
+    from zeronotesamba_amd.pretext import PretextTrainer, train_epoch, val_epoch
+    g = golden("step_eval.npz")
+    B, T, tau = int(g["B"]), int(g["T"]), float(g["tau"])
+    ref = g["lr1e-6_losses"]
+    loader = [[cnn_ref.synth_vqt(200 + it, (B, 2, 96, T))] for it in range(3)]
+    crit = NTXent(B, tau)
+    m = make_model(int(g["seed"]))
+    opt = torch.optim.Adam(m.parameters(), lr=1e-6)
+    m.anchor.pretrained.cv1.weight.grad = torch.ones_like(m.anchor.pretrained.cv1.weight)
+    got = val_epoch(m, loader[:1], crit, opt)
+    np.testing.assert_allclose(got, ref[0], atol=2e-5)
+    assert m.anchor.pretrained.cv1.weight.grad is None or not m.anchor.pretrained.cv1.weight.grad.any()   # :552 zero_grad
+    assert not m.training
+    for make_opt in (lambda ps: torch.optim.Adam(ps, lr=1e-6), lambda ps: Adam(ps, lr=1e-6)):
+        m = make_model(int(g["seed"]))
+        for br in (m.anchor, m.postve):
+            br.pretrained.dp.p = 0.0
+        m2, l, p, n = train_epoch(m, loader, crit, make_opt(m.parameters()))
+        assert m2 is m and m.training
+        np.testing.assert_allclose([l, p, n], ref.mean(axis=0), atol=2e-5)
+        for k, v in m.named_parameters():
+            _check_stats(v, g[f"lr1e-6_s2_param_{k}_stats"], g[f"lr1e-6_s2_param_{k}_samples"], rtol=1e-5)
+    m = make_model(int(g["seed"]))
+    for br in (m.anchor, m.postve):
+        br.pretrained.dp.p = 0.0
+    tr = PretextTrainer(m, batch_len=B, temperature=tau, lr=1e-6)
+    np.testing.assert_allclose(tr.train_epoch(loader), ref.mean(axis=0), atol=2e-5)
+    for k, v in m.named_parameters():
+        _check_stats(v, g[f"lr1e-6_s2_param_{k}_stats"], g[f"lr1e-6_s2_param_{k}_samples"], rtol=1e-5)
+    # and with dropout really on the epoch still runs and differs
+    m = make_model(int(g["seed"]))
+    _, l_do, _, _ = train_epoch(m, loader, crit, torch.optim.Adam(m.parameters(), lr=1e-6))
+    assert np.isfinite(l_do) and abs(l_do - ref[:, 0].mean()) > 1e-6
+
+
+def _ds_model(seed):
+    from zeronotesamba_amd.models.models import DS_CNN
+    sd = {k[len("anchor."):]: v for k, v in cnn_ref.synth_state_dict(seed, 2.0).items() if k.startswith("anchor.")}
+    m = DS_CNN()
+    m.load_state_dict(sd)
+    return m.to(DEV), sd
+
+
+def test_clmr_against_the_reference(golden):
+    """pt_task "clmr" (pretext.py:494-511, 567-583) against vectors captured from the REAL reference's DS_CNN + NTXent +
+    Adam(lr=1e-5) (tests/golden/clmr_eval.npz): the fused PretextTrainer (one stack over the 2B rows) step by step --
+    losses, embeddings, gradients, parameters after steps 1 and 3 -- then the module-level train_epoch / val_epoch
+    return values.  Gradients additionally at 1e-4 against the oracle with the device's decisions replayed."""
+    from oracle import step_ref
+    from replay_util import device_decisions, rel_l2
+    from zeronotesamba_amd.models.loss_functions import NTXent
+    from zeronotesamba_amd.pretext import PretextTrainer, train_epoch, val_epoch
+    g = golden("clmr_eval.npz")
+    B, T, tau, lr = int(g["B"]), int(g["T"]), float(g["tau"]), float(g["lr"])
+    ref = g["losses"]
+    m, sd = _ds_model(int(g["seed"]))
+    tr = PretextTrainer(m, batch_len=B, temperature=tau, lr=lr, train=False)
+    assert tr.pt_task == "clmr"
+    for it in range(3):
+        batch = cnn_ref.synth_vqt(210 + it, (B, 2, 96, T))
+        x = tr.stack_inputs(batch)
+        if it == 0:
+            replay, emb = device_decisions(x, tr.P, B, stack_B=2 * B)
+            np.testing.assert_allclose(emb[:B].cpu().numpy(), g["s0_anc_emb"], atol=1e-4)
+            np.testing.assert_allclose(emb[B:].cpu().numpy(), g["s0_pos_emb"], atol=1e-4)
+        out3 = tr.step(x).tolist()
+        tol = 2e-5 if it == 0 else 5e-4        # sign-like early Adam steps at lr 1e-5 amplify rounding noise in g
+        np.testing.assert_allclose(out3, ref[it], atol=tol)
+        if it == 0:
+            op = step_ref.OracleParams(sd, lr)
+            step_ref.clmr_step(op, batch, B, tau, step_opt=False, replay=replay)
+            og = op.grads()
+            for k, v in m.named_parameters():
+                _check_stats(v.grad, g[f"s0_grad_{k}_stats"], g[f"s0_grad_{k}_samples"], rtol=1e-2, srtol=0.1)
+                assert rel_l2(v.grad, og[k]) <= 1e-4, (k, rel_l2(v.grad, og[k]))
+        if it in (0, 2):
+            for k, v in m.named_parameters():
+                _check_stats(v, g[f"s{it}_param_{k}_stats"], g[f"s{it}_param_{k}_samples"], rtol=1e-5 if it == 0 else 1e-4)
+    vals = [tr.evaluate(tr.stack_inputs(cnn_ref.synth_vqt(220 + it, (B, 2, 96, T)))).tolist() for it in range(2)]
+    np.testing.assert_allclose(vals, g["val_after"], atol=5e-4)
+    # module-level epoch functions, the reference's own call structure
+    loader = [[cnn_ref.synth_vqt(210 + it, (B, 2, 96, T))] for it in range(3)]
+    vloader = [[cnn_ref.synth_vqt(220 + it, (B, 2, 96, T))] for it in range(2)]
+    crit = NTXent(B, tau)
+    m, _ = _ds_model(int(g["seed"]))
+    m.pretrained.dp.p = 0.0
+    opt = torch.optim.Adam(m.parameters(), lr=lr)
+    _, l, p, n = train_epoch(m, loader, crit, opt, pt_task="clmr")
+    np.testing.assert_allclose([l, p, n], ref.mean(axis=0), atol=5e-4)
+    np.testing.assert_allclose(val_epoch(m, vloader, crit, opt, pt_task="clmr"), g["val_after"].mean(axis=0), atol=5e-4)
+
+
 def test_rccl_bucketed_allreduce_on_the_launch_streams():
     """The data-parallel step on a REAL RCCL group (one rank: this box has one GPU).  The bucketed async all-reduces
     run on RCCL's stream between the backward kernels; with one rank they must leave the step bitwise unchanged,

@@ -92,6 +92,80 @@ def test_pretext_step_matches_reference(golden):
                                 rtol=1e-5 if it == 0 else 1e-4)
 
 
+def ds_state_dict(seed, gain):
+    return {k[len("anchor."):]: v for k, v in cnn_ref.synth_state_dict(seed, gain).items() if k.startswith("anchor.")}
+
+
+def test_clmr_step_matches_reference(golden):
+    """pt_task "clmr" (pretext.py:494-511): the oracle's shared-DS_CNN step against vectors from the real reference."""
+    g = golden("clmr_eval.npz")
+    B, T, tau, lr = int(g["B"]), int(g["T"]), float(g["tau"]), float(g["lr"])
+    op = step_ref.OracleParams(ds_state_dict(int(g["seed"]), float(g["gain"])), lr)
+    for it in range(3):
+        batch = cnn_ref.synth_vqt(210 + it, (B, 2, 96, T))
+        loss, cp, cn, a, p = step_ref.clmr_step(op, batch, B, tau)
+        ref = g["losses"][it]
+        tol = 5e-6 if it == 0 else 5e-4   # sign-like early Adam steps at lr 1e-5 amplify rounding noise in g
+        assert abs(loss - ref[0]) < tol and abs(cp - ref[1]) < tol and abs(cn - ref[2]) < tol
+        if it == 0:
+            np.testing.assert_allclose(a.numpy(), g["s0_anc_emb"], atol=2e-6)
+            np.testing.assert_allclose(p.numpy(), g["s0_pos_emb"], atol=2e-6)
+            for k, gr in op.grads().items():
+                check_stats(gr, g[f"s0_grad_{k}_stats"], g[f"s0_grad_{k}_samples"])
+        if it in (0, 2):
+            for k, v in op.values().items():
+                check_stats(v, g[f"s{it}_param_{k}_stats"], g[f"s{it}_param_{k}_samples"], rtol=1e-5 if it == 0 else 1e-4)
+    with torch.no_grad():
+        for it in range(2):
+            batch = cnn_ref.synth_vqt(220 + it, (B, 2, 96, T))
+            a = cnn_ref.ds_cnn_forward(op.sd, "", batch[:, 0:1])
+            p = cnn_ref.ds_cnn_forward(op.sd, "", batch[:, 1:2])
+            loss, cp, cn = ntxent_ref.ntxent(a, p, B, tau)
+            ref = g["val_after"][it]
+            assert abs(loss.item() - ref[0]) < 5e-4 and abs(cp - ref[1]) < 5e-4 and abs(cn - ref[2]) < 5e-4
+
+
+def own_decisions(sd, prefix, x):
+    """The max-pool / ReLU decisions a plain forward of the oracle takes, in the replay record's format."""
+    import torch.nn.functional as F
+    rec, out = {}, x
+    for li, (name, cin, cout, kh, kw, pool) in enumerate(cnn_ref.LAYERS):
+        z = F.conv2d(out, sd[f"{prefix}pretrained.{name}.weight"], sd[f"{prefix}pretrained.{name}.bias"],
+                     padding=(kh // 2, kw // 2))
+        am = None
+        if pool > 1:
+            Bn, C, H, Tt = z.shape
+            am = z.reshape(Bn, C, H // pool, pool, Tt).argmax(dim=3).to(torch.uint8)
+            z = F.max_pool2d(z, (pool, 1))
+        out = F.relu(z)
+        rec[li] = (out != 0, am)
+    return rec
+
+
+def test_mask_replay_of_own_decisions_is_the_identity():
+    """Mask-replay mode (cnn_ref.cnn_forward(replay=...)) fed the oracle's OWN decisions reproduces the plain step bit
+    for bit, and counts zero overridden decisions; fed ONE flipped pool decision it reports exactly that flip."""
+    B, T, tau = 2, 40, 0.25
+    sd = cnn_ref.synth_state_dict(5, 2.0)
+    batch = cnn_ref.synth_vqt(200, (B, 2, 96, T))
+    op = step_ref.OracleParams(sd, 1e-6)
+    l0, _, _, a0, p0 = step_ref.pretext_step(op, batch, B, tau, step_opt=False)
+    g0 = op.grads()
+    rec = {"anchor": own_decisions(sd, "anchor.", batch[:, 0:1]), "postve": own_decisions(sd, "postve.", batch[:, 1:2])}
+    op2 = step_ref.OracleParams(sd, 1e-6)
+    flips = {}
+    l1, _, _, a1, p1 = step_ref.pretext_step(op2, batch, B, tau, step_opt=False, replay=rec, flips=flips)
+    assert l0 == l1 and torch.equal(a0, a1) and torch.equal(p0, p1)
+    g1 = op2.grads()
+    assert all(torch.equal(g0[k], g1[k]) for k in g0)
+    assert all(n_am == 0 and n_mask == 0 for per in flips.values() for (n_am, n_mask, _n) in per.values())
+    am = rec["anchor"][1][1]
+    am[0, 0, 0, 0] = (am[0, 0, 0, 0] + 1) % 3
+    flips = {}
+    step_ref.pretext_step(step_ref.OracleParams(sd, 1e-6), batch, B, tau, step_opt=False, replay=rec, flips=flips)
+    assert flips["anchor"][1][0] == 1 and flips["postve"][1][0] == 0
+
+
 def test_finetune_step_matches_reference(golden):
     g = golden("finetune.npz")
     T = int(g["T"])

@@ -79,6 +79,86 @@ def test_host_filter_bank_matches_oracle():
         np.testing.assert_allclose(t[32:], right, rtol=1e-13, atol=1e-16)
 
 
+def test_general_resampy_loop_equals_the_two_to_one_specialisation():
+    """oracle.vqt_ref.resample2 is resampy's interpolation loop specialised by hand to the exact 2:1 ratio (frac = 0,
+    eta = 0, 32 + 31 taps).  The GENERAL loop (offset / eta interpolation between table entries, interp_delta), restated
+    literally, must give the same float32 bits for even, odd and short inputs -- and behave like a resampler at other
+    ratios (3:1 decimation and 2:3 interpolation of a slow sinusoid)."""
+    rng = np.random.default_rng(0)
+    for n in (2000, 2001, 777, 130, 65):
+        x = (0.3 * rng.standard_normal(n)).astype(np.float32)
+        a = vqt_ref.librosa_resample_general(x, 2, 1)
+        b = vqt_ref.resample2(x)
+        assert a.dtype == b.dtype == np.float32 and a.shape == b.shape == ((n + 1) // 2,)
+        assert np.array_equal(a, b), n
+        assert np.array_equal(vqt_ref.librosa_resample_general(x, 16000, 8000), b)      # ratio, not the rates, matters
+    x = np.sin(2 * np.pi * 0.01 * np.arange(3000)).astype(np.float32)
+    y = vqt_ref.resample_general(x, 3, 1)
+    assert y.shape == (1000,) and np.abs(y[50:-50] - np.sin(2 * np.pi * 0.03 * np.arange(1000))[50:-50]).max() < 5e-3
+    y = vqt_ref.resample_general(x, 2, 3)
+    assert y.shape == (4500,)
+    assert np.abs(y[100:-100] - np.sin(2 * np.pi * 0.01 * np.arange(4500) / 1.5)[100:-100]).max() < 1e-3
+    # the taps the specialisation (and the HIP kernel) uses are the table entries the general loop lands on
+    left, right = vqt_ref.decimate2_taps()
+    win = vqt_ref.kaiser_fast_half_window() * 0.5
+    assert len(left) == 32 and len(right) == 31
+    assert np.array_equal(left, win[np.arange(32) * 256]) and np.array_equal(right, win[256 + np.arange(31) * 256])
+
+
+@pytest.mark.parametrize("mode", ["vqt", "cqt"])
+def test_brute_force_correlator_bounds_the_fft_form(mode):
+    """A second derivation that shares nothing with the FFT / sparsify / fold chain: the plain time-domain correlation
+    N * sum_n b_k[-n] y[n] built from the constant_q definition.  librosa's form differs from it only by the
+    negative-frequency half it never forms and the entries sparsify_rows(1 %) drops; both are bounded analytically per
+    (bin, frame) and the bound must hold everywhere -- for the oracle's response and for the folded FIR bank the HIP
+    kernel applies (numpy AND the product's C++ bank)."""
+    import ctypes as C
+    y = noise(5, 20000 if mode == "vqt" else 40000)
+    V = vqt_ref.xqt_complex(y, mode)
+    bf = vqt_ref.brute_force_response(y, mode)
+    worst = 0.0
+    for i in range(8):
+        k0 = 96 - 12 * (i + 1)
+        nf = min(V.shape[1], bf[i].shape[1])
+        d = np.abs(V[k0:k0 + 12, :nf] - bf[i][:, :nf])
+        bound = vqt_ref.brute_force_bound(y, mode, i)[:, :nf]
+        assert (d <= bound * 1.001 + 1e-7).all(), i
+        worst = max(worst, (d / np.abs(bf[i]).max()).max())
+    assert worst < 0.06          # observed 0.6 % (octaves 0-5) .. 4.4 % (octave 7, n_fft = 16) of the loudest bin
+    # the folded FIR bank against N * b_k[(-n) mod N]: per tap within the dropped + negative L1 mass
+    from zeronotesamba_amd import _lib
+    L = _lib.lib()
+    mid = 0 if mode == "vqt" else 1
+    nfft = (C.c_int * 8)()
+    assert L.zns_xqt_host_bank(mid, nfft, None, 0, None) == 0
+    nf8 = list(nfft)
+    tot = sum(12 * n * 2 for n in nf8)
+    fir = (C.c_float * tot)()
+    assert L.zns_xqt_host_bank(mid, nfft, fir, tot, None) == 0
+    fir = np.frombuffer(fir, dtype=np.float32)
+    g = vqt_ref.gamma_for(mode)
+    bank, full_lengths = vqt_ref.filter_bank(mode)
+    fmin_t = float(np.min(vqt_ref.FMIN * (2.0 ** (np.arange(96, dtype=float) / 12))[-12:]))
+    o = 0
+    for i, g_np in enumerate(vqt_ref.time_domain_bank(mode)):
+        N = nf8[i]
+        g_cc = fir[o:o + 12 * N * 2].reshape(12, N, 2)
+        g_cc = g_cc[..., 0] + 1j * g_cc[..., 1]
+        o += 12 * N * 2
+        basis, lengths = vqt_ref.octave_filters(16000 / 2.0 ** i, fmin_t * 2.0 ** -i, g)
+        b = (basis * (lengths[:, None] / float(N))).astype(np.complex64).astype(np.complex128)
+        F = np.fft.fft(b, axis=1)
+        kept = bank[i]["fft_basis"].astype(np.complex128) / np.sqrt(2.0 ** i)
+        mass = np.abs(F[:, :N // 2 + 1] - kept).sum(axis=1) + np.abs(F[:, N // 2 + 1:]).sum(axis=1)
+        k0 = 96 - 12 * (i + 1)
+        scale = np.sqrt(2.0 ** i) / np.sqrt(full_lengths[k0:k0 + 12])
+        direct = N * b[:, (-np.arange(N)) % N] * scale[:, None]
+        for gk in (g_np, g_cc):
+            assert (np.abs(gk - direct) <= (mass * scale)[:, None] * 1.001 + 1e-7).all(), i
+        # and the 1 % quantile really drops less than 1 % of each row's L1 mass
+        assert (np.abs(F[:, :N // 2 + 1] - kept).sum(axis=1) < 0.01 * np.abs(F[:, :N // 2 + 1]).sum(axis=1) + 1e-12).all()
+
+
 # ------------------------------------------------------------------ GPU: kernel vs oracle
 def lin_err(got_log, ref_log):
     """Compare in the linear domain relative to the loudest bin: log() amplifies fp32 noise in near-silent bins."""

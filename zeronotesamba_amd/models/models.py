@@ -26,18 +26,19 @@ def _fresh_seed() -> int:
 class _StackFn(torch.autograd.Function):
     """nbr DS_CNN stacks (conv stack [+ head]) as one autograd node.
 
-    forward(x [nbr*B,1,96,T], nbr, B, train, seed, with_head, *params) -> emb [nbr*B,T] (or h [nbr*B,128,T])
+    forward(x [nbr*B,1,96,T], nbr, B, drop_p, seed, with_head, *params) -> emb [nbr*B,T] (or h [nbr*B,128,T])
+    drop_p: dropout probability of this call (the module's `dp.p` in train mode, 0 in eval mode).
     """
 
     @staticmethod
-    def forward(ctx, x, nbr, B, train, seed, with_head, *params):
+    def forward(ctx, x, nbr, B, drop_p, seed, with_head, *params):
         P = _ops.StackParams.from_flat(params, nbr)
         pneeds = ctx.needs_input_grad[6:]
         need_grad = any(pneeds)
-        drop_p = _ops.DROP_P if train else 0.0
+        drop_p = float(drop_p)
         emb, acts, argm = _ops.stack_forward(x, P, B, drop_p, seed, save=need_grad, with_head=with_head)
         ctx.nbr, ctx.B, ctx.with_head = nbr, B, with_head
-        ctx.inv_keep = 1.0 / (1.0 - drop_p) if train else 1.0
+        ctx.inv_keep = 1.0 / (1.0 - drop_p)
         ctx.conv_needs = any(n for i, n in enumerate(pneeds) if (i % 18) < 16)
         ctx.pneeds = pneeds
         if need_grad:
@@ -116,6 +117,13 @@ class _CNN(nn.Module):
 
         self.dp = nn.Dropout(p=0.1)
 
+    def drop_p(self) -> float:
+        """Dropout probability in effect: `self.dp.p` (models.py:30) while training, 0 in eval mode."""
+        p = float(self.dp.p) if (self.training and self.dp.training) else 0.0
+        if not 0.0 <= p < 1.0:
+            raise ValueError(f"dropout probability has to be in [0, 1), but got {p}")
+        return p
+
     def conv_params(self) -> List[torch.Tensor]:
         out: List[torch.Tensor] = []
         for name, *_ in _ops.LAYERS:
@@ -131,8 +139,9 @@ class _CNN(nn.Module):
         x = _prep_input(x, "_CNN input")
         params = self.conv_params()
         dummy = [params[0].new_zeros(1), params[0].new_zeros(1)]  # head slots, unused when with_head=False
-        seed = _fresh_seed() if self.training else 0
-        return _StackFn.apply(x, 1, x.shape[0], self.training, seed, False, *params, *dummy)
+        drop_p = self.drop_p()
+        seed = _fresh_seed() if drop_p > 0.0 else 0
+        return _StackFn.apply(x, 1, x.shape[0], drop_p, seed, False, *params, *dummy)
 
 
 class DS_CNN(nn.Module):
@@ -157,8 +166,9 @@ class DS_CNN(nn.Module):
         -- x: input (vqt) [B, 1, 96, T] -> [B, T]
         """
         x = _prep_input(x, "DS_CNN input")
-        seed = _fresh_seed() if self.training else 0
-        return _StackFn.apply(x, 1, x.shape[0], self.training, seed, True, *self.stack_params())
+        drop_p = self.pretrained.drop_p()
+        seed = _fresh_seed() if drop_p > 0.0 else 0
+        return _StackFn.apply(x, 1, x.shape[0], drop_p, seed, True, *self.stack_params())
 
 
 class Pretext_CNN(nn.Module):
@@ -180,7 +190,8 @@ class Pretext_CNN(nn.Module):
         anc = _prep_input(anc, "anchor input")
         pos = _prep_input(pos, "positive input")
         same_dev = anc.device == pos.device == self.anchor.fc1.weight.device == self.postve.fc1.weight.device
-        if not same_dev or anc.shape != pos.shape or self.anchor.training != self.postve.training:
+        drop_p = self.anchor.pretrained.drop_p()
+        if not same_dev or anc.shape != pos.shape or drop_p != self.postve.pretrained.drop_p():
             # the reference's branch-per-device placement (pretext.py:199-200): run the branches separately
             with torch.cuda.device(anc.device):
                 a = self.anchor(anc)
@@ -189,8 +200,8 @@ class Pretext_CNN(nn.Module):
             return a, p
         B = anc.shape[0]
         x = torch.cat([anc, pos], dim=0)
-        seed = _fresh_seed() if self.training else 0
-        emb = _StackFn.apply(x, 2, B, self.training, seed, True, *self.anchor.stack_params(),
+        seed = _fresh_seed() if drop_p > 0.0 else 0
+        emb = _StackFn.apply(x, 2, B, drop_p, seed, True, *self.anchor.stack_params(),
                              *self.postve.stack_params())
         return emb[:B], emb[B:]
 

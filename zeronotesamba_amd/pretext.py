@@ -73,6 +73,8 @@ def val_epoch(model: torch.nn.Module, val_loader: Iterable, criterion: NTXent,
     with torch.no_grad():
         for batch_idx, [batch] in enumerate(val_loader):
             anchors, postves = split_batch(batch, device)
+            if optimizer is not None:
+                optimizer.zero_grad()        # pretext.py:552,572 clear the gradients here too
             if pt_task == "zerons":
                 anc_emb, pos_emb = model(anchors, postves)
             else:
@@ -228,6 +230,20 @@ class PretextTrainer:
                                    "was built (e.g. model.to(...)); build the trainer after placing the model")
 
     # ------------------------------------------------------------------ one step
+    def _drop_p(self) -> float:
+        """Dropout probability of a training step: the modules' own `dp.p` (models.py:30), 0 when train=False."""
+        if not self.train_mode:
+            return 0.0
+        m = self.model
+        cnns = (m.anchor.pretrained, m.postve.pretrained) if self.pt_task == "zerons" else (m.pretrained,)
+        ps = {float(c.dp.p) for c in cnns}
+        if len(ps) != 1:
+            raise ValueError(f"PretextTrainer: the branches have different dropout probabilities {sorted(ps)}")
+        p = ps.pop()
+        if not 0.0 <= p < 1.0:
+            raise ValueError(f"dropout probability has to be in [0, 1), but got {p}")
+        return p
+
     def _next_seed(self) -> int:
         s = (self.seed * 0x9E3779B1 + self.step_count * 0x85EBCA77 + self.rank * 0xC2B2AE3D + 1) & 0x7FFFFFFF
         return s
@@ -245,7 +261,7 @@ class PretextTrainer:
         T = x.shape[-1]
         if B > self.batch_len:
             raise IndexError(f"PretextTrainer: {B} rows > batch_len={self.batch_len}")
-        drop_p = _ops.DROP_P if self.train_mode else 0.0
+        drop_p = self._drop_p()
         inv_keep = 1.0 / (1.0 - drop_p)
         seed = self._next_seed()
         Bs = 2 * B // self.nbr     # rows per stack: B for the twin launch, 2B for the shared (clmr) network
