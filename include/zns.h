@@ -122,11 +122,12 @@ int zns_down_bwd_f32(const float* a, const float* p, const float* dout, size_t n
                      float* da, float* dp, void* stream);
 
 /* ------------------------------------------------------------------ NT-Xent (loss_functions.py:24-55)
- * a, p: [rows, D] (rows <= batch_len).  out3 (device, 3 floats): loss, mean anchor/positive
- * cosine, mean anchor/negative cosine -- all divided by batch_len as the reference does.
- * ga/gp (nullable): d(loss*grad_scale)/da, /dp. */
+ * a, p: [rows, D] (rows <= batch_len; any batch size, as config.yaml's batch_size).  out3 (device, 3 floats): loss,
+ * mean anchor/positive cosine, mean anchor/negative cosine -- all divided by batch_len as the reference does.
+ * ga/gp (nullable): d(loss*grad_scale)/da, /dp.  ws: zns_ntxent_workspace_bytes(rows) bytes of device scratch. */
+size_t zns_ntxent_workspace_bytes(int rows);
 int zns_ntxent_f32(const float* a, const float* p, int rows, int D, int batch_len, float tau,
-                   float* out3, float* ga, float* gp, float grad_scale, void* stream);
+                   float* out3, float* ga, float* gp, float grad_scale, void* ws, size_t ws_bytes, void* stream);
 
 /* BCELoss(mean) forward + backward (loader.py:16, epochs.py:61): loss (device scalar), dout nullable */
 int zns_bce_f32(const float* out, const float* target, size_t n, float* loss, float* dout,

@@ -122,7 +122,8 @@ def cnn_forward(
                 own = z5.detach().argmax(dim=3)   # first maximum wins, as max_pool2d
                 n_am = int((own != am.long()).sum())
                 out = torch.gather(z5, 3, am.long().unsqueeze(3)).squeeze(3)
-            n_mask = int(((out.detach() > 0) != mask).sum()) if replay_scale == 1.0 else -1
+            # with dropout in the record only one direction is visible: kept by the record, zeroed by this run's ReLU
+            n_mask = int(((out.detach() > 0) != mask).sum()) if replay_scale == 1.0 else int((mask & (out.detach() <= 0)).sum())
             if flips is not None:
                 flips[li] = (n_am, n_mask, mask.numel())
             out = out * mask.to(out.dtype) * replay_scale

@@ -38,6 +38,19 @@ def rel_l2(got: torch.Tensor, ref: torch.Tensor) -> float:
     return float((got - ref).norm() / ref.norm().clamp_min(1e-30))
 
 
+def grad_err(name: str, got: torch.Tensor, refs) -> float:
+    """rel_l2 of one parameter gradient against refs[name].  The single-element fc1.bias gradient is a sum of signed
+    terms (sum of d_emb * emb * (1 - emb)) that can cancel to far below its terms (near-collinear embeddings: 1e-6 from
+    terms of 1e-3), so its error is measured on the scale of the same sum weighted by the activations -- the largest
+    fc1.weight gradient entry -- whenever that is larger than the bias gradient itself."""
+    ref = refs[name].detach().double()
+    err = float((got.detach().cpu().double() - ref).norm())
+    scale = float(ref.norm())
+    if name.endswith("fc1.bias"):
+        scale = max(scale, float(refs[name[:-len("bias")] + "weight"].detach().abs().max()))
+    return err / max(scale, 1e-30)
+
+
 def flip_summary(flips) -> str:
     """'anchor: cv2 3 pool / 1 relu of 1.0e+06; ...' for the layers where a decision was overridden."""
     parts: List[str] = []

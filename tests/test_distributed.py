@@ -7,14 +7,23 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from zeronotesamba_amd.distributed import GradBucketReducer, make_buckets, shard_units
+from zeronotesamba_amd.distributed import GradBucketReducer, broadcast_tensors, make_buckets, shard_units
 
 
-def test_shard_units_partition():
-    for n, w in ((1440, 8), (10, 3), (2, 4), (0, 2)):
-        parts = [list(shard_units(n, r, w)) for r in range(w)]
-        assert sorted(sum(parts, [])) == list(range(n))
-        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+def test_shard_units_are_equal_length():
+    """Every rank must run the same number of steps (each step is a collective): shards have EQUAL length."""
+    for n, w in ((1440, 8), (10, 3), (2, 4), (0, 2), (7, 2)):
+        parts = [shard_units(n, r, w) for r in range(w)]
+        assert len({len(p) for p in parts}) == 1                       # equal length on every rank
+        flat = sum(parts, [])
+        assert len(set(flat)) == len(flat) == (n // w) * w             # drop_last: disjoint, remainder dropped
+        assert all(0 <= u < n for u in flat)
+        if n:
+            padded = [shard_units(n, r, w, drop_last=False) for r in range(w)]
+            assert len({len(p) for p in padded}) == 1 and len(padded[0]) == -(-n // w)
+            assert set(sum(padded, [])) == set(range(n))               # padding: every unit is seen at least once
+    with pytest.raises(ValueError):
+        shard_units(4, 2, 2)
 
 
 def test_make_buckets_tiles_in_backward_order():
@@ -50,8 +59,13 @@ def _worker(rank, world, port, q):
         ok = torch.allclose(flat, expect) and abs(scale - 1.0 / world) < 1e-12
         # mean gradient == what one process would see on the concatenated batches (8e: local NT-Xent, averaged)
         ok = ok and torch.allclose(flat * scale, torch.arange(n, dtype=torch.float32) * 1.5)
+        # replicas that were initialised differently start from rank 0's state (PretextTrainer.broadcast_state)
+        pr = torch.full((5,), float(rank + 7))
+        mo = torch.full((3,), float(rank))
+        broadcast_tensors((pr, mo), src=0)
+        ok = ok and bool((pr == 7.0).all()) and bool((mo == 0.0).all())
         # every rank owns whole clips
-        mine = list(shard_units(7, rank, world))
+        mine = list(shard_units(7, rank, world, drop_last=False))
         q.put((rank, bool(ok), mine))
     finally:
         dist.destroy_process_group()
@@ -69,8 +83,8 @@ def test_bucketed_allreduce_gloo_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res)
-    units = sorted(sum((m for _, _, m in res), []))
-    assert units == list(range(7))
+    units = sum((m for _, _, m in res), [])
+    assert set(units) == set(range(7)) and len(units) == 8      # equal shards of 4, one unit wrapped around
 
 
 def test_gaps_in_buckets_are_rejected():

@@ -186,7 +186,7 @@ def test_full_size_step_against_the_cpu_oracle():
       (2) the oracle on its own decisions: flip-tolerant 3e-2 (one flipped element reroutes a gradient column)."""
     from conftest import host_threads
     from oracle import step_ref
-    from replay_util import device_decisions, flip_summary, rel_l2, total_flips
+    from replay_util import device_decisions, flip_summary, grad_err, rel_l2, total_flips
     from zeronotesamba_amd import _ops
     from zeronotesamba_amd.pretext import PretextTrainer
     B, T, tau = 16, 512, 0.25
@@ -211,7 +211,7 @@ def test_full_size_step_against_the_cpu_oracle():
     print("  decisions overridden:", flip_summary(flips), "(total %d)" % total_flips(flips))
     worst = 0.0
     for name, p in model.named_parameters():
-        rel = rel_l2(p.grad, ref[name])
+        rel = grad_err(name, p.grad, ref)
         worst = max(worst, rel)
         print(f"  {name:36s} rel {rel:.2e}  |ref| {ref[name].norm().item():.3e}")
         assert rel <= 1e-4, (name, rel)

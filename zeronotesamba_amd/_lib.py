@@ -37,7 +37,9 @@ SIGNATURES = {
                                                    c_fp, C.c_size_t, c_fp]),
     "zns_down_fwd_f32": (C.c_int, [c_fp, c_fp, C.c_size_t, C.c_int, c_fp, c_fp]),
     "zns_down_bwd_f32": (C.c_int, [c_fp, c_fp, c_fp, C.c_size_t, C.c_int, c_fp, c_fp, c_fp]),
-    "zns_ntxent_f32": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_float, c_fp, c_fp, c_fp, C.c_float, c_fp]),
+    "zns_ntxent_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "zns_ntxent_f32": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_float, c_fp, c_fp, c_fp, C.c_float, c_fp,
+                                 C.c_size_t, c_fp]),
     "zns_bce_f32": (C.c_int, [c_fp, c_fp, C.c_size_t, c_fp, c_fp, C.c_float, c_fp]),
     "zns_adam_step_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_int, C.c_float, c_fp]),

@@ -36,8 +36,38 @@ def require_device(t: torch.Tensor, what: str) -> None:
         raise RuntimeError(f"zeronotesamba_amd: {what} must be float32, got {t.dtype}")
 
 
-def stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def stream_ptr(device=None) -> int:
+    """hipStream_t of torch's current stream ON `device` (default: the current device)."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class on_device:
+    """Make `t`'s device the current HIP device for the enclosed C-ABI calls (kernels launch on the CURRENT device; the
+    stream, the workspace and every pointer must belong to it).  Switches only when needed; restores on exit."""
+
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, t: torch.Tensor):
+        self.idx = t.device.index if t.device.index is not None else torch.cuda.current_device()
+
+    def __enter__(self):
+        self.prev = torch.cuda.current_device()
+        if self.prev != self.idx:
+            torch.cuda.set_device(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev != self.idx:
+            torch.cuda.set_device(self.prev)
+        return False
+
+
+def same_device(ref: torch.Tensor, tensors, what: str) -> None:
+    """Every tensor of one call must live on ref's device: the library never copies between GPUs."""
+    for t in tensors:
+        if t is not None and t.device != ref.device:
+            raise RuntimeError(f"zeronotesamba_amd: {what}: tensors on different devices ({ref.device} and {t.device}); "
+                               "move the module and its inputs to ONE device (or call the branches separately)")
 
 
 def workspace(nbytes: int, device: torch.device, slot: int = 0) -> torch.Tensor:
@@ -51,6 +81,7 @@ def workspace(nbytes: int, device: torch.device, slot: int = 0) -> torch.Tensor:
 
 
 def conv_workspace_bytes(nbr: int, B: int, T: int) -> int:
+    """Largest per-layer workspace of one stack pass (split-K factors follow the CURRENT device's CU count)."""
     L = _lib.lib()
     need = 0
     for (name, cin, cout, kh, kw, pool), H in zip(LAYERS, H_IN):
@@ -72,14 +103,17 @@ def conv_fwd(li: int, nbr: int, B: int, T: int, x: torch.Tensor, w: Sequence[tor
         am = torch.empty((nbr * B, cout, H // pool, T), dtype=torch.uint8, device=x.device)
     spec = None
     if want_argmax:  # = activations are being saved for a backward pass: keep the input spectrum for backward-weights
-        nspec = _lib.lib().zns_conv2d_spectrum_bytes(nbr, B, T, cin, cout, kh, kw, H)
+        with on_device(x):
+            nspec = _lib.lib().zns_conv2d_spectrum_bytes(nbr, B, T, cin, cout, kh, kw, H)
         if nspec:
             spec = torch.empty(nspec // 4, dtype=torch.float32, device=x.device)
-    rc = _lib.lib().zns_conv2d_fwd_f32(nbr, B, T, cin, cout, kh, kw, H, pool, x.data_ptr(), _pp(w), _pp(b),
-                                       y.data_ptr(), am.data_ptr() if am is not None else None,
-                                       float(drop_p), int(seed) & 0xFFFFFFFF, li,
-                                       spec.data_ptr() if spec is not None else None,
-                                       ws.data_ptr(), ws.numel(), stream_ptr())
+    same_device(x, (*w, *b, ws), name)
+    with on_device(x):
+        rc = _lib.lib().zns_conv2d_fwd_f32(nbr, B, T, cin, cout, kh, kw, H, pool, x.data_ptr(), _pp(w), _pp(b),
+                                           y.data_ptr(), am.data_ptr() if am is not None else None,
+                                           float(drop_p), int(seed) & 0xFFFFFFFF, li,
+                                           spec.data_ptr() if spec is not None else None,
+                                           ws.data_ptr(), ws.numel(), stream_ptr(x.device))
     _lib.check(rc, f"zns_conv2d_fwd_f32[{name}]")
     return y, am, spec
 
@@ -90,11 +124,13 @@ def conv_dgrad(li: int, nbr: int, B: int, T: int, dz: torch.Tensor, w: Sequence[
     name, cin, cout, kh, kw, pool = LAYERS[li]
     H = H_IN[li]
     dx = torch.empty((nbr * B, cin, H * prev_pool, T), dtype=torch.float32, device=dz.device)
-    rc = _lib.lib().zns_conv2d_dgrad_f32(nbr, B, T, cin, cout, kh, kw, H, dz.data_ptr(), _pp(w), dx.data_ptr(),
-                                         x.data_ptr() if x is not None else None, float(inv_keep),
-                                         prev_argmax.data_ptr() if prev_argmax is not None else None, prev_pool,
-                                         dzspec.data_ptr() if dzspec is not None else None,
-                                         ws.data_ptr(), ws.numel(), stream_ptr())
+    same_device(dz, (*w, x, prev_argmax, dzspec, ws), name)
+    with on_device(dz):
+        rc = _lib.lib().zns_conv2d_dgrad_f32(nbr, B, T, cin, cout, kh, kw, H, dz.data_ptr(), _pp(w), dx.data_ptr(),
+                                             x.data_ptr() if x is not None else None, float(inv_keep),
+                                             prev_argmax.data_ptr() if prev_argmax is not None else None, prev_pool,
+                                             dzspec.data_ptr() if dzspec is not None else None,
+                                             ws.data_ptr(), ws.numel(), stream_ptr(dz.device))
     _lib.check(rc, f"zns_conv2d_dgrad_f32[{name}]")
     return dx
 
@@ -104,24 +140,43 @@ def conv_wgrad(li: int, nbr: int, B: int, T: int, dz: torch.Tensor, x: torch.Ten
                xspec: Optional[torch.Tensor] = None, dzspec_out: Optional[torch.Tensor] = None) -> None:
     name, cin, cout, kh, kw, pool = LAYERS[li]
     H = H_IN[li]
-    rc = _lib.lib().zns_conv2d_wgrad_f32(nbr, B, T, cin, cout, kh, kw, H, dz.data_ptr(), x.data_ptr(), _pp(dw),
-                                         _pp(db), int(bool(accumulate)),
-                                         xspec.data_ptr() if xspec is not None else None,
-                                         dzspec_out.data_ptr() if dzspec_out is not None else None,
-                                         ws.data_ptr(), ws.numel(), stream_ptr())
+    same_device(dz, (x, *dw, *db, xspec, dzspec_out, ws), name)
+    with on_device(dz):
+        rc = _lib.lib().zns_conv2d_wgrad_f32(nbr, B, T, cin, cout, kh, kw, H, dz.data_ptr(), x.data_ptr(), _pp(dw),
+                                             _pp(db), int(bool(accumulate)),
+                                             xspec.data_ptr() if xspec is not None else None,
+                                             dzspec_out.data_ptr() if dzspec_out is not None else None,
+                                             ws.data_ptr(), ws.numel(), stream_ptr(dz.device))
     _lib.check(rc, f"zns_conv2d_wgrad_f32[{name}]")
 
 
 def dz_spectrum(li: int, nbr: int, B: int, T: int, device) -> Optional[torch.Tensor]:
     """Scratch for the dZ spectrum backward-weights hands to backward-data of the same layer (None: not applicable)."""
     name, cin, cout, kh, kw, pool = LAYERS[li]
-    n = _lib.lib().zns_conv2d_dz_spectrum_bytes(nbr, B, T, cin, cout, kh, kw, H_IN[li])
+    with torch.cuda.device(device):
+        n = _lib.lib().zns_conv2d_dz_spectrum_bytes(nbr, B, T, cin, cout, kh, kw, H_IN[li])
     return torch.empty(n // 4, dtype=torch.float32, device=device) if n else None
+
+
+def ntxent(a: torch.Tensor, p: torch.Tensor, rows: int, D: int, batch_len: int, tau: float, out3: torch.Tensor,
+           ga: Optional[torch.Tensor], gp: Optional[torch.Tensor], grad_scale: float = 1.0) -> None:
+    """zns_ntxent_f32 on a/p's device and current stream (scratch from workspace slot 2)."""
+    same_device(a, (p, out3, ga, gp), "NTXent (the reference moves anc_emb to the positives' device first, pretext.py:484)")
+    L = _lib.lib()
+    ws = workspace(L.zns_ntxent_workspace_bytes(rows), a.device, slot=2)
+    with on_device(a):
+        rc = L.zns_ntxent_f32(a.data_ptr(), p.data_ptr(), rows, D, batch_len, float(tau), out3.data_ptr(),
+                              ga.data_ptr() if ga is not None else None, gp.data_ptr() if gp is not None else None,
+                              float(grad_scale), ws.data_ptr(), ws.numel(), stream_ptr(a.device))
+    _lib.check(rc, "zns_ntxent_f32")
 
 
 def head_fwd(nbr: int, B: int, T: int, h: torch.Tensor, w: Sequence[torch.Tensor], b: Sequence[torch.Tensor]):
     emb = torch.empty((nbr * B, T), dtype=torch.float32, device=h.device)
-    rc = _lib.lib().zns_head_fwd_f32(nbr, B, T, 128, h.data_ptr(), _pp(w), _pp(b), emb.data_ptr(), stream_ptr())
+    same_device(h, (*w, *b), "head_fwd")
+    with on_device(h):
+        rc = _lib.lib().zns_head_fwd_f32(nbr, B, T, 128, h.data_ptr(), _pp(w), _pp(b), emb.data_ptr(),
+                                         stream_ptr(h.device))
     _lib.check(rc, "zns_head_fwd_f32")
     return emb
 
@@ -130,9 +185,11 @@ def head_bwd(nbr: int, B: int, T: int, h: torch.Tensor, emb: torch.Tensor, demb:
              w: Sequence[torch.Tensor], inv_keep: float, dw: Sequence[torch.Tensor], db: Sequence[torch.Tensor],
              accumulate: bool, ws: torch.Tensor) -> torch.Tensor:
     dz = torch.empty_like(h)
-    rc = _lib.lib().zns_head_bwd_f32(nbr, B, T, 128, h.data_ptr(), emb.data_ptr(), demb.data_ptr(), _pp(w),
-                                     float(inv_keep), dz.data_ptr(), _pp(dw), _pp(db), int(bool(accumulate)),
-                                     ws.data_ptr(), ws.numel(), stream_ptr())
+    same_device(h, (emb, demb, *w, *dw, *db, ws), "head_bwd")
+    with on_device(h):
+        rc = _lib.lib().zns_head_bwd_f32(nbr, B, T, 128, h.data_ptr(), emb.data_ptr(), demb.data_ptr(), _pp(w),
+                                         float(inv_keep), dz.data_ptr(), _pp(dw), _pp(db), int(bool(accumulate)),
+                                         ws.data_ptr(), ws.numel(), stream_ptr(h.device))
     _lib.check(rc, "zns_head_bwd_f32")
     return dz
 
@@ -168,7 +225,8 @@ def stack_forward(x: torch.Tensor, P: StackParams, B: int, drop_p: float, seed: 
     """x: [nbr*B, 1, 96, T] -> (emb [nbr*B, T] or None, acts [y1..y8], argmax {layer: u8})."""
     nbr = P.nbr
     T = x.shape[-1]
-    ws = workspace(conv_workspace_bytes(nbr, B, T), x.device, ws_slot)
+    with on_device(x):
+        ws = workspace(conv_workspace_bytes(nbr, B, T), x.device, ws_slot)
     acts: List[torch.Tensor] = []
     argm: Dict[int, torch.Tensor] = {}
     cur = x
@@ -199,7 +257,8 @@ def stack_backward(x: torch.Tensor, P: StackParams, B: int, acts: List[torch.Ten
     """
     nbr = P.nbr
     T = x.shape[-1]
-    ws = workspace(conv_workspace_bytes(nbr, B, T), x.device, ws_slot)
+    with on_device(x):
+        ws = workspace(conv_workspace_bytes(nbr, B, T), x.device, ws_slot)
     if demb is not None:
         dz = head_bwd(nbr, B, T, acts[7], emb, demb, P.fc_w, inv_keep, G.fc_w, G.fc_b, accumulate, ws)
         if after_layer:

@@ -35,7 +35,7 @@ using namespace zns;
 extern "C" {
 
 const char* zns_last_error(void) { return g_err; }
-int zns_version(void) { return 102; }   // 101: dzspec_out / dzspec, 102: stem mix + RMS gate
+int zns_version(void) { return 103; }   // 101: dzspec_out / dzspec, 102: stem mix + RMS gate, 103: NT-Xent workspace (any batch size)
 int zns_set_impl(int impl) {
     const int prev = g_impl;
     g_impl = impl;

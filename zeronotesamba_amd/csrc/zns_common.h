@@ -68,4 +68,14 @@ struct MPtr2 {
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Function attributes (MaxDynamicSharedMemorySize) and device allocations are PER DEVICE: "done once" state is keyed
+// by the calling thread's current device, so a process that drives several GPUs (e.g. the reference's branch-per-device
+// placement, pretext.py:199-200) configures each of them.
+constexpr int ZNS_MAX_DEVICES = 64;
+static inline int current_device_slot() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
+    return d % ZNS_MAX_DEVICES;
+}
+
 }  // namespace zns

@@ -703,16 +703,12 @@ static __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, MPtr2
 
 
 static int device_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-            cus = n;
-        else
-            cus = 256;   // MI355X; also the answer when no device is visible (workspace queries on a CPU box)
-    }
-    return cus;
+    static int cus[ZNS_MAX_DEVICES] = {};
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 256;   // no device visible (workspace queries on a CPU box)
+    int& c = cus[dev % ZNS_MAX_DEVICES];
+    if (c == 0) c = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    return c;
 }
 
 // Split-K factor for backward-weights.  One workgroup per CU is resident (LDS), every workgroup does the same

@@ -632,19 +632,21 @@ static int run_spec_inv(const float* S, float* out, int nb, int C, int H, int T,
 
 template <class C>
 static int set_lds_f(void (*kern)(CoreArgs)) {
-    static bool done = false;
-    if (!done) {
+    static bool done[ZNS_MAX_DEVICES] = {};
+    const int d = current_device_slot();
+    if (!done[d]) {
         ZNS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-        done = true;
+        done[d] = true;
     }
     return ZNS_OK;
 }
 template <class C>
 static int set_lds_fw(void (*kern)(WgArgs)) {
-    static bool done = false;
-    if (!done) {
+    static bool done[ZNS_MAX_DEVICES] = {};
+    const int d = current_device_slot();
+    if (!done[d]) {
         ZNS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-        done = true;
+        done[d] = true;
     }
     return ZNS_OK;
 }

@@ -88,19 +88,21 @@ size_t mfma_workspace_bytes(const ConvArgs& a) {
 
 template <class C>
 static int set_lds(void (*kern)(CoreArgs)) {
-    static bool done = false;
-    if (!done) {
+    static bool done[ZNS_MAX_DEVICES] = {};
+    const int d = current_device_slot();
+    if (!done[d]) {
         ZNS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-        done = true;
+        done[d] = true;
     }
     return ZNS_OK;
 }
 template <class C>
 static int set_lds_wg(void (*kern)(WgArgs)) {
-    static bool done = false;
-    if (!done) {
+    static bool done[ZNS_MAX_DEVICES] = {};
+    const int d = current_device_slot();
+    if (!done[d]) {
         ZNS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES));
-        done = true;
+        done[d] = true;
     }
     return ZNS_OK;
 }

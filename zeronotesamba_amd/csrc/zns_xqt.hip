@@ -11,6 +11,7 @@
 // sqrt(2^i) rescale, resampy's tap-by-tap float32 accumulation with float64 products, float32 /sqrt(0.5).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <complex>
 #include <mutex>
 #include <vector>
@@ -41,7 +42,7 @@ struct Bank {
     DecTaps* taps = nullptr;   // device: float64 decimation taps
     bool ready = false;
 };
-Bank g_bank[2];
+Bank g_bank[2][ZNS_MAX_DEVICES];   // per (mode, device): the FIR bank lives in that device's memory
 std::mutex g_bank_mu;
 
 double sinc_pi(double x) { return x == 0.0 ? 1.0 : std::sin(M_PI * x) / (M_PI * x); }
@@ -147,7 +148,7 @@ void build_fir(int mode, std::vector<std::vector<std::complex<double>>>& fir, in
 
 int ensure_bank(int mode, Bank** out) {
     std::lock_guard<std::mutex> lk(g_bank_mu);
-    Bank& b = g_bank[mode];
+    Bank& b = g_bank[mode][current_device_slot()];
     if (!b.ready) {
         std::vector<std::vector<std::complex<double>>> fir;
         build_fir(mode, fir, b.n_fft);
@@ -192,57 +193,121 @@ void pyramid(int n, int* len, size_t* off) {
 }  // namespace
 
 
-// thread -> 4 consecutive outputs of one clip.  The 72-sample input window is fetched once (18 aligned 16-byte
-// loads when the rows allow it) and kept in registers as float64; the 63 float64 taps are wave-uniform (scalar
-// cache).  Exact restatement of resampy's accumulation: y (float32) += weight (float64) * x, i.e. the float64
-// product-sum is rounded to float32 after EVERY tap, left wing i = 0..31 first, then the right wing.
-__global__ void __launch_bounds__(256) decimate2_kernel(const float* __restrict__ in, long long in_stride, int n_in,
-                                                        float* __restrict__ out, long long out_stride, int n_quads,
-                                                        const DecTaps* __restrict__ tp, int n_clips, int vec_ok) {
-    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= (long long)n_clips * n_quads) return;
-    const int q = (int)(o % n_quads), c = (int)(o / n_quads);
-    const float* x = in + (long long)c * in_stride;
-    const int t0 = q * 4;
-    const int n_out = n_in / 2;   // resampy: int(n * 0.5); librosa pads to ceil with zeros
-    const int base = 2 * t0 - 32; // xw[j] = x[base + j]
-    double xw[72];
-    if (vec_ok) {
+// ---------------------------------------------------------------------------------------------------------
+// Decimation chain: `nlev` consecutive 2:1 decimations of the pyramid in ONE launch.
+//
+// Arithmetic (exact restatement of resampy's accumulation): y (float32) += weight (float64) * x, i.e. the float64
+// product-sum is rounded to float32 after EVERY tap, left wing i = 0..31 first, then the right wing k = 0..30.  One
+// tap = v_fma_f64 + v_cvt_f32_f64 + v_cvt_f64_f32, three dependent half-rate instructions: 12.35 cycles per
+// wave-instruction-triple per SIMD measured (tools/ubench_f64.hip), i.e. 12.7e12 taps/s per chip -- that issue rate,
+// not HBM, bounds this kernel (1.0e7 taps per 10 s clip, 3.2 ms per 4096 clips at the ceiling).
+//
+// Structure.  A block owns 4*GL outputs of the chain's LAST level of one clip and computes, level by level, exactly
+// the (overlapping) ranges the next level needs; every level's outputs go to global memory (the filter kernel reads the
+// pyramid) and, as float64, into an LDS window that is the next level's input -- a sample is converted to float64 once,
+// not once per thread that touches it.  Thread = 4 consecutive outputs (group g), 4 independent accumulation chains.
+// Window layout: local sample m (origin = 2*T0 - 32, a multiple of 8) lives at [(m & 7) * S + (m >> 3)]: the 14 samples
+// a chunk of 8 taps needs are then 14 conflict-free ds_read_b64 (consecutive lanes -> consecutive columns) at
+// compile-time offsets from one per-chunk pointer.  Taps arrive 8 at a time through the scalar cache (all 63 at once
+// need 126 SGPRs: the previous kernel spilled 52 of them to VGPR lanes).
+//
+// Ranges.  Level j (1..nlev) of block b computes groups g < G[j] starting at output T0[j]:
+//   T0[nlev] = b * 4 * GL, G[nlev] = GL;   T0[j] = 2 T0[j+1] - 32, G[j] = 2 G[j+1] + 18   (what level j+1 reads)
+// Outputs outside [0, n_out) are zeros (outside the signal; [n_out, ceil(n/2)) is librosa's fix_length padding).
+// A level's outputs are written to global memory by the block that owns them (its share of the last level, scaled).
+constexpr int DC_S = 265;                 // columns per window row: windows of up to 8 * DC_S = 2120 samples (G <= 256)
+constexpr int DC_WIN = 8 * DC_S;
+constexpr int DC_MAXLEV = 4;
+
+struct DecChain {
+    const float* src;                     // level feeding the chain: [n_clips][src_stride]
+    long long src_stride;
+    int src_len;
+    int src_vec;                          // rows are 16-byte aligned: float4 staging loads
+    int nlev, GL, blocks_per_clip;
+    float* dst[DC_MAXLEV];                // outputs of level j = 1..nlev
+    long long dst_stride[DC_MAXLEV];
+    int n_out[DC_MAXLEV];                 // resampy's output count of that level: int(n_in * 0.5)
+    int G[DC_MAXLEV];
+};
+
+__device__ __forceinline__ int dc_addr(int m) { return (m & 7) * DC_S + (m >> 3); }
+
+// NT taps of one wing: xv[n] = window sample (8 * col0 + 1 + n) of this thread's group; left wing tap u of output k reads
+// xv[7 + 2k - u], right wing xv[2k + u]
+template <int NT, bool LEFT>
+__device__ __forceinline__ void dc_chunk(const double* __restrict__ p, const double* __restrict__ w, double (&acc)[4]) {
+    double xv[14];
 #pragma unroll
-        for (int v = 0; v < 18; ++v) {
-            const int i0 = base + 4 * v;
-            float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i0 >= 0 && i0 < n_in) f = *reinterpret_cast<const float4*>(x + i0);
-            xw[4 * v + 0] = (double)f.x;
-            xw[4 * v + 1] = (i0 + 1 < n_in) ? (double)f.y : 0.0;
-            xw[4 * v + 2] = (i0 + 2 < n_in) ? (double)f.z : 0.0;
-            xw[4 * v + 3] = (i0 + 3 < n_in) ? (double)f.w : 0.0;
+    for (int n = 0; n < 6 + NT; ++n) xv[n] = p[((1 + n) & 7) * DC_S + ((1 + n) >> 3)];
+    double wv[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) wv[u] = w[u];
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] = (double)(float)(acc[k] + wv[u] * xv[LEFT ? 7 + 2 * k - u : 2 * k + u]);
+}
+
+__global__ void __launch_bounds__(256) decimate_chain_kernel(DecChain P, const DecTaps* __restrict__ tp) {
+    extern __shared__ __attribute__((aligned(16))) double dwin[];     // [2][DC_WIN] (one buffer when nlev == 1)
+    const int clip = blockIdx.x / P.blocks_per_clip, b = blockIdx.x - clip * P.blocks_per_clip;
+    // T0[j] - 32 = 2 (T0[j+1] - 32)  ->  closed form, no runtime-indexed array
+    auto T0 = [&](int j) { return 32 + (b * 4 * P.GL - 32) * (1 << (P.nlev - 1 - j)); };
+    // ---- stage the source window [o, o + 8 G[0] + 72) as float64, zero outside the signal
+    {
+        const int o = 2 * T0(0) - 32, nwin = 8 * P.G[0] + 72;
+        const float* x = P.src + (long long)clip * P.src_stride;
+        if (P.src_vec) {
+            for (int q = threadIdx.x; q < nwin / 4; q += 256) {
+                const int i0 = o + 4 * q;
+                float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i0 >= 0 && i0 < P.src_len) f = *reinterpret_cast<const float4*>(x + i0);   // rows are padded to 4
+                double* d = dwin + ((4 * q) & 7) * DC_S + (q >> 1);
+                d[0] = (double)f.x;
+                d[DC_S] = (i0 + 1 < P.src_len) ? (double)f.y : 0.0;
+                d[2 * DC_S] = (i0 + 2 < P.src_len) ? (double)f.z : 0.0;
+                d[3 * DC_S] = (i0 + 3 < P.src_len) ? (double)f.w : 0.0;
+            }
+        } else {
+            for (int m = threadIdx.x; m < nwin; m += 256) {
+                const int i0 = o + m;
+                dwin[dc_addr(m)] = (i0 >= 0 && i0 < P.src_len) ? (double)x[i0] : 0.0;
+            }
         }
-    } else {
+    }
+    __syncthreads();
+    for (int j = 0; j < P.nlev; ++j) {
+        const double* __restrict__ src = dwin + (j & 1) * DC_WIN;
+        double* __restrict__ nxt = dwin + ((j + 1) & 1) * DC_WIN;
+        const bool last = j + 1 == P.nlev;
+        const int own_lo = (b * 4 * P.GL) << (P.nlev - 1 - j), own_hi = ((b + 1) * 4 * P.GL) << (P.nlev - 1 - j);
+        float* __restrict__ y = P.dst[j] + (long long)clip * P.dst_stride[j];
+        const int T0j = T0(j);
+        for (int g = threadIdx.x; g < P.G[j]; g += 256) {
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};   // always holds a float32-representable value
+            const double* p = src + g + 3;
+#pragma unroll 1
+            for (int c = 0; c < 4; ++c, --p) dc_chunk<8, true>(p, tp->l + 8 * c, acc);
+            p = src + g + 4;
+#pragma unroll 1
+            for (int c = 0; c < 3; ++c, ++p) dc_chunk<8, false>(p, tp->r + 8 * c, acc);
+            dc_chunk<7, false>(p, tp->r + 24, acc);
+            const int t0 = T0j + 4 * g;
+            float v[4];
 #pragma unroll
-        for (int j = 0; j < 72; ++j) {
-            const int i0 = base + j;
-            xw[j] = (i0 >= 0 && i0 < n_in) ? (double)x[i0] : 0.0;
+            for (int k = 0; k < 4; ++k)
+                v[k] = (t0 + k >= 0 && t0 + k < P.n_out[j]) ? (float)acc[k] / 0.70710677f : 0.f;   // y_hat /= sqrt(0.5), float32
+            if (t0 >= own_lo && t0 < own_hi && (long long)t0 < P.dst_stride[j])
+                *reinterpret_cast<float4*>(y + t0) = make_float4(v[0], v[1], v[2], v[3]);
+            if (!last) {
+                double* d = nxt + (4 * (g & 1)) * DC_S + (g >> 1);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[k * DC_S] = (double)v[k];
+            }
         }
+        __syncthreads();
     }
-    // a tap outside the signal contributes w * 0 = +0: identical to resampy skipping it
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};   // always holds a float32-representable value
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        const double w = tp->l[i];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] = (double)(float)(acc[k] + w * xw[32 + 2 * k - i]);
-    }
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {
-        const double w = tp->r[j];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] = (double)(float)(acc[k] + w * xw[32 + 2 * k + 1 + j]);
-    }
-    float y[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) y[k] = (t0 + k < n_out) ? (float)acc[k] / 0.70710677f : 0.f;   // y_hat /= sqrt(0.5) in float32
-    *reinterpret_cast<float4*>(out + (long long)c * out_stride + t0) = make_float4(y[0], y[1], y[2], y[3]);
 }
 
 struct XqtLevels {
@@ -417,13 +482,49 @@ int zns_xqt_f32(const float* wav, int n_clips, int n_samples, int sample_rate, i
             L.stride[i] = (long long)(((size_t)len[i] + 3) / 4 * 4);
         }
     }
-    for (int i = 1; i < XQ_OCT; ++i) {
-        const int n_quads = (len[i] + 3) / 4;
-        const long long total = (long long)n_clips * n_quads;
-        const int vec_ok = (L.stride[i - 1] % 4 == 0) && ((uintptr_t)L.y[i - 1] % 16 == 0);
-        hipLaunchKernelGGL(decimate2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, L.y[i - 1],
-                           L.stride[i - 1], len[i - 1], (float*)L.y[i], L.stride[i], n_quads, b->taps, n_clips, vec_ok);
-        ZNS_LAUNCH_CHECK();
+    // decimation pyramid: levels 1..7, grouped into chains (one launch each).  Default plan: the three big levels on
+    // their own (no recomputed halo where 7/8 of the taps are), the four small ones fused (their launches are
+    // latency-bound: 6.5 us each for a 32-clip batch).  ZNS_XQT_PLAN="n1,n2,.." overrides the grouping (tuning aid).
+    {
+        int plan[XQ_OCT] = {1, 1, 1, 4}, nplan = 4;
+        if (const char* e = getenv("ZNS_XQT_PLAN")) {
+            nplan = 0;
+            int tot = 0;
+            for (const char* q = e; *q && nplan < XQ_OCT;) {
+                const int v = atoi(q);
+                ZNS_CHECK_ARG(v >= 1 && v <= DC_MAXLEV, "ZNS_XQT_PLAN: chain of %d levels (1..%d)", v, DC_MAXLEV);
+                plan[nplan++] = v;
+                tot += v;
+                while (*q && *q != ',') ++q;
+                if (*q == ',') ++q;
+            }
+            ZNS_CHECK_ARG(tot == XQ_OCT - 1, "ZNS_XQT_PLAN must cover the %d decimation levels", XQ_OCT - 1);
+        }
+        static const int gl_max[DC_MAXLEV + 1] = {0, 256, 119, 50, 16};   // G[0] = (GL + 18) 2^(nlev-1) - 18 <= DC_S - 9
+        int a = 0;   // source level of the next chain
+        for (int c = 0; c < nplan; ++c) {
+            const int nlev = plan[c];
+            DecChain P{};
+            P.src = L.y[a];
+            P.src_stride = L.stride[a];
+            P.src_len = len[a];
+            P.src_vec = (L.stride[a] % 4 == 0) && ((uintptr_t)L.y[a] % 16 == 0);
+            P.nlev = nlev;
+            P.GL = gl_max[nlev];
+            P.blocks_per_clip = (int)((L.stride[a + nlev] + 4 * P.GL - 1) / (4 * P.GL));
+            for (int j = 0; j < nlev; ++j) {
+                P.dst[j] = (float*)L.y[a + 1 + j];
+                P.dst_stride[j] = L.stride[a + 1 + j];
+                P.n_out[j] = len[a + j] / 2;   // resampy: int(n * 0.5); librosa pads to ceil with zeros
+            }
+            P.G[nlev - 1] = P.GL;
+            for (int j = nlev - 2; j >= 0; --j) P.G[j] = 2 * P.G[j + 1] + 18;
+            const size_t lds = (size_t)(nlev > 1 ? 2 : 1) * DC_WIN * sizeof(double);
+            hipLaunchKernelGGL(decimate_chain_kernel, dim3((unsigned)((size_t)n_clips * P.blocks_per_clip)), dim3(256), lds,
+                               st, P, b->taps);
+            ZNS_LAUNCH_CHECK();
+            a += nlev;
+        }
     }
     const int n_frames = zns_xqt_frames(n_samples);
     int max_fft = 0;

@@ -31,11 +31,25 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, world, local
 
 
-def shard_units(n_units: int, rank: int, world: int) -> range:
-    """Clips (= 16-item batches) owned by `rank`: contiguous blocks, sizes differing by at most one."""
-    base, rem = divmod(n_units, world)
-    start = rank * base + min(rank, rem)
-    return range(start, start + base + (1 if rank < rem else 0))
+def shard_units(n_units: int, rank: int, world: int, drop_last: bool = True) -> List[int]:
+    """Clips (= 16-item batches) owned by `rank`.  Every rank gets the SAME number of units: each training step
+    all-reduces the gradient, so a rank holding one batch more than the others would wait in RCCL for peers that have
+    already left the epoch (until the watchdog kills the job).  As torch's DistributedSampler: drop_last=True drops
+    the n_units % world remainder (contiguous blocks of n_units // world); drop_last=False pads the tail by wrapping
+    around to the first units, so nothing is skipped and a few units are seen twice per epoch."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError(f"rank {rank} not in a world of {world}")
+    if drop_last:
+        per = n_units // world
+        return list(range(rank * per, (rank + 1) * per))
+    per = -(-n_units // world) if n_units > 0 else 0
+    return [(rank * per + i) % n_units for i in range(per)]
+
+
+def broadcast_tensors(tensors: Sequence[torch.Tensor], src: int = 0, group: Any = None) -> None:
+    """Overwrite every rank's `tensors` with rank `src`'s (replica initialisation: parameters, Adam moments)."""
+    for t in tensors:
+        dist.broadcast(t, src=src, group=group)
 
 
 def make_buckets(layer_slices: Sequence[Tuple[str, int, int]], min_floats: int) -> List[Tuple[str, int, int]]:

@@ -20,8 +20,10 @@ class _BCEFn(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=o.device)
         need = ctx.needs_input_grad[0]
         dout = torch.empty_like(o) if need else None
-        rc = _lib.lib().zns_bce_f32(o.data_ptr(), t.data_ptr(), o.numel(), loss.data_ptr(),
-                                    dout.data_ptr() if need else None, 1.0, _ops.stream_ptr())
+        _ops.same_device(o, (t,), "BCELoss")
+        with _ops.on_device(o):
+            rc = _lib.lib().zns_bce_f32(o.data_ptr(), t.data_ptr(), o.numel(), loss.data_ptr(),
+                                        dout.data_ptr() if need else None, 1.0, _ops.stream_ptr(o.device))
         _lib.check(rc, "zns_bce_f32")
         if need:
             ctx.save_for_backward(dout)

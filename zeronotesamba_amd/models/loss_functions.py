@@ -24,10 +24,7 @@ class _NTXentFn(torch.autograd.Function):
         need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         ga = torch.empty_like(a) if need else None
         gp = torch.empty_like(p) if need else None
-        rc = _lib.lib().zns_ntxent_f32(a.data_ptr(), p.data_ptr(), rows, D, batch_len, float(temperature),
-                                       out3.data_ptr(), ga.data_ptr() if need else None,
-                                       gp.data_ptr() if need else None, 1.0, _ops.stream_ptr())
-        _lib.check(rc, "zns_ntxent_f32")
+        _ops.ntxent(a, p, rows, D, batch_len, temperature, out3, ga, gp)
         if need:
             ctx.save_for_backward(ga, gp)
         ctx.mark_non_differentiable(out3)

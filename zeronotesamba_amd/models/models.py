@@ -192,12 +192,9 @@ class Pretext_CNN(nn.Module):
         same_dev = anc.device == pos.device == self.anchor.fc1.weight.device == self.postve.fc1.weight.device
         drop_p = self.anchor.pretrained.drop_p()
         if not same_dev or anc.shape != pos.shape or drop_p != self.postve.pretrained.drop_p():
-            # the reference's branch-per-device placement (pretext.py:199-200): run the branches separately
-            with torch.cuda.device(anc.device):
-                a = self.anchor(anc)
-            with torch.cuda.device(pos.device):
-                p = self.postve(pos)
-            return a, p
+            # the reference's branch-per-device placement (pretext.py:199-200): run the branches separately, each on
+            # the device its input and weights live on (every C-ABI call switches to its tensors' device, _ops.on_device)
+            return self.anchor(anc), self.postve(pos)
         B = anc.shape[0]
         x = torch.cat([anc, pos], dim=0)
         seed = _fresh_seed() if drop_p > 0.0 else 0
@@ -213,8 +210,10 @@ class _DownFn(torch.autograd.Function):
         a = a.contiguous()
         p = p.contiguous()
         out = torch.empty_like(a)
-        rc = _lib.lib().zns_down_fwd_f32(a.data_ptr(), p.data_ptr(), a.numel(), reduction, out.data_ptr(),
-                                         _ops.stream_ptr())
+        _ops.same_device(a, (p,), "Down_CNN combine")
+        with _ops.on_device(a):
+            rc = _lib.lib().zns_down_fwd_f32(a.data_ptr(), p.data_ptr(), a.numel(), reduction, out.data_ptr(),
+                                             _ops.stream_ptr(a.device))
         _lib.check(rc, "zns_down_fwd_f32")
         ctx.reduction = reduction
         ctx.save_for_backward(a, p)
@@ -226,8 +225,9 @@ class _DownFn(torch.autograd.Function):
         a, p = ctx.saved_tensors
         dout = dout.contiguous()
         da, dp = torch.empty_like(a), torch.empty_like(p)
-        rc = _lib.lib().zns_down_bwd_f32(a.data_ptr(), p.data_ptr(), dout.data_ptr(), a.numel(), ctx.reduction,
-                                         da.data_ptr(), dp.data_ptr(), _ops.stream_ptr())
+        with _ops.on_device(a):
+            rc = _lib.lib().zns_down_bwd_f32(a.data_ptr(), p.data_ptr(), dout.data_ptr(), a.numel(), ctx.reduction,
+                                             da.data_ptr(), dp.data_ptr(), _ops.stream_ptr(a.device))
         _lib.check(rc, "zns_down_bwd_f32")
         return da, dp, None
 
@@ -249,5 +249,7 @@ class Down_CNN(nn.Module):
         """
         from .. import _lib
         anc_emb, pos_emb = self.pretext(anc, pos)
+        if anc_emb.device != pos_emb.device:      # branch-per-device placement: combine where the positives live
+            anc_emb = anc_emb.to(pos_emb.device)
         red = _lib.ZNS_REDUCE_MEAN if self.reduction == "mean" else _lib.ZNS_REDUCE_MAX
         return _DownFn.apply(anc_emb, pos_emb, red)

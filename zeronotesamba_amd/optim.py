@@ -41,8 +41,10 @@ class Adam(torch.optim.Optimizer):
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 if not p.is_contiguous():
                     raise RuntimeError("zeronotesamba_amd.optim.Adam: parameters must be contiguous")
-                rc = L.zns_adam_step_f32(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
-                                         st["exp_avg_sq"].data_ptr(), p.numel(), group["lr"], b1, b2, group["eps"],
-                                         st["step"], 1.0, _ops.stream_ptr())
+                _ops.same_device(p, (g,), "Adam")
+                with _ops.on_device(p):
+                    rc = L.zns_adam_step_f32(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(),
+                                             st["exp_avg_sq"].data_ptr(), p.numel(), group["lr"], b1, b2,
+                                             group["eps"], st["step"], 1.0, _ops.stream_ptr(p.device))
                 _lib.check(rc, "zns_adam_step_f32")
         return loss

@@ -27,25 +27,35 @@ from .models.models import DS_CNN, Pretext_CNN
 _BUCKET_MIN_FLOATS = 1 << 20  # fire an all-reduce once >= 4 MiB of gradients are ready
 
 
-def split_batch(batch: torch.Tensor, device) -> Tuple[torch.Tensor, torch.Tensor]:
-    """pretext.py:476-477: anchors = batch[:,0:1], postves = batch[:,1:2], moved to the device."""
-    return batch[:, 0:1, :, :].to(device), batch[:, 1:2, :, :].to(device)
+def split_batch(batch: torch.Tensor, device, device1=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """pretext.py:476-477: anchors = batch[:,0:1] -> device0, postves = batch[:,1:2] -> device1."""
+    return batch[:, 0:1, :, :].to(device), batch[:, 1:2, :, :].to(device if device1 is None else device1)
+
+
+def _branch_devices(model: torch.nn.Module, pt_task: str):
+    """(device0, device1) of pretext.py:24-25,199-200: the anchor branch's and the positive branch's device (the same
+    one unless the caller placed the branches on two GPUs as the reference does); "clmr": the one model's device."""
+    if pt_task == "zerons" and hasattr(model, "anchor") and hasattr(model, "postve"):
+        return next(model.anchor.parameters()).device, next(model.postve.parameters()).device
+    d = next(model.parameters()).device
+    return d, d
 
 
 def train_epoch(model: torch.nn.Module, train_loader: Iterable, criterion: NTXent,
                 optimizer: torch.optim.Optimizer, pt_task: str = "zerons") -> Tuple[torch.nn.Module, float, float, float]:
     """pretext.py:453-524."""
-    device = next(model.parameters()).device
-    acc = torch.zeros(3, dtype=torch.float64, device=device)
-    model.train()
-    batch_idx = -1
     if pt_task not in ("zerons", "clmr"):
         raise ValueError("Which pretext task are we running?")
+    device0, device1 = _branch_devices(model, pt_task)
+    acc = torch.zeros(3, dtype=torch.float64, device=device1)
+    model.train()
+    batch_idx = -1
     for batch_idx, [batch] in enumerate(train_loader):
-        anchors, postves = split_batch(batch, device)
+        anchors, postves = split_batch(batch, device0, device1)
         optimizer.zero_grad()
         if pt_task == "zerons":
             anc_emb, pos_emb = model(anchors, postves)
+            anc_emb = anc_emb.to(device1)                      # pretext.py:484 (a no-op on one device)
         else:  # clmr: one shared DS_CNN on both views (pretext.py:494-511)
             anc_emb = model(anchors)
             pos_emb = model(postves)
@@ -64,19 +74,20 @@ def train_epoch(model: torch.nn.Module, train_loader: Iterable, criterion: NTXen
 def val_epoch(model: torch.nn.Module, val_loader: Iterable, criterion: NTXent,
               optimizer: Optional[torch.optim.Optimizer] = None, pt_task: str = "zerons") -> Tuple[float, float, float]:
     """pretext.py:527-592 (model.eval(), torch.no_grad())."""
-    device = next(model.parameters()).device
-    acc = torch.zeros(3, dtype=torch.float64, device=device)
-    model.eval()
-    batch_idx = -1
     if pt_task not in ("zerons", "clmr"):
         raise ValueError("Which pretext task are we running?")
+    device0, device1 = _branch_devices(model, pt_task)
+    acc = torch.zeros(3, dtype=torch.float64, device=device1)
+    model.eval()
+    batch_idx = -1
     with torch.no_grad():
         for batch_idx, [batch] in enumerate(val_loader):
-            anchors, postves = split_batch(batch, device)
+            anchors, postves = split_batch(batch, device0, device1)
             if optimizer is not None:
                 optimizer.zero_grad()        # pretext.py:552,572 clear the gradients here too
             if pt_task == "zerons":
                 anc_emb, pos_emb = model(anchors, postves)
+                anc_emb = anc_emb.to(device1)
             else:
                 anc_emb = model(anchors)
                 pos_emb = model(postves)
@@ -113,14 +124,22 @@ class ShiftBank:
             raise ValueError(f"bank must be (N, 2, 96, T), got {tuple(b.shape)}")
         if b.shape[3] - crop < batch_len:
             raise ValueError("not enough distinct start frames for batch_len crops")
+        import numpy as np
         self.bank = b.to(device).contiguous()
         self.batch_len, self.crop = batch_len, crop
         self.n_clips, self.bank_T = b.shape[0], b.shape[3]
+        self.order = np.arange(self.n_clips)          # logical clip (after shuffles) -> physical bank row
 
-    def shuffle_(self, generator: Optional[torch.Generator] = None) -> None:
-        """np.random.shuffle(train_bank) (pretext.py:282), on the device."""
-        perm = torch.randperm(self.n_clips, generator=generator).to(self.bank.device)
-        self.bank = self.bank[perm].contiguous()
+    def shuffle_(self, rng=None) -> None:
+        """np.random.shuffle(train_bank) (pretext.py:282) without moving 13.8 GB: the permutation is drawn exactly as
+        numpy draws it for an in-place shuffle of the first axis (`rng.permutation(n)` consumes the same stream as
+        `rng.shuffle(bank)`: one Fisher-Yates pass), from numpy's global state by default so that `np.random.seed`
+        reproduces the reference's clip order, and is applied through the clip -> bank-row table `self.order` that
+        `batch()` consults.  rng: None (np.random), a np.random.RandomState or a np.random.Generator."""
+        import numpy as np
+        r = np.random if rng is None else rng
+        perm = np.asarray(r.permutation(self.n_clips))
+        self.order = self.order[perm]
 
     def draw_starts(self, rng=None) -> List[int]:
         import random as _random
@@ -136,10 +155,13 @@ class ShiftBank:
         if len(starts) != self.batch_len or min(starts) < 0 or max(starts) + self.crop > self.bank_T:
             raise ValueError("bad start frames")
         dev = self.bank.device
-        idx = torch.tensor([[clip] * self.batch_len, list(starts)], dtype=torch.int32).to(dev, non_blocking=True)
+        row = int(self.order[clip])
+        idx = torch.tensor([[row] * self.batch_len, list(starts)], dtype=torch.int32).to(dev, non_blocking=True)
         out = torch.empty((2 * self.batch_len, 1, _ops.N_BINS, self.crop), dtype=torch.float32, device=dev)
-        rc = _lib.lib().zns_shift_gather_f32(self.bank.data_ptr(), self.bank_T, idx[0].data_ptr(), idx[1].data_ptr(),
-                                             self.batch_len, self.crop, out.data_ptr(), _ops.stream_ptr())
+        with _ops.on_device(self.bank):
+            rc = _lib.lib().zns_shift_gather_f32(self.bank.data_ptr(), self.bank_T, idx[0].data_ptr(),
+                                                 idx[1].data_ptr(), self.batch_len, self.crop, out.data_ptr(),
+                                                 _ops.stream_ptr(dev))
         _lib.check(rc, "zns_shift_gather_f32")
         self._keep = idx     # the index tensor must outlive the enqueued kernel
         return out
@@ -154,10 +176,17 @@ class PretextTrainer:
 
     def __init__(self, model: torch.nn.Module, batch_len: int = 16, temperature: float = 0.25, lr: float = 1e-6,
                  betas: Tuple[float, float] = (0.9, 0.999), eps: float = 1e-8, seed: int = 0,
-                 process_group: Any = None, train: bool = True, pt_task: Optional[str] = None):
+                 process_group: Any = None, train: bool = True, pt_task: Optional[str] = None,
+                 data_parallel: Optional[bool] = None):
         """model: Pretext_CNN (pt_task "zerons", two independent branches) or DS_CNN (pt_task "clmr": ONE
         network applied to both views, pretext.py:494-511 -- run here as a single stack over the 2B rows, so
-        its weight gradient is the sum over both views exactly as two autograd passes would give)."""
+        its weight gradient is the sum over both views exactly as two autograd passes would give).
+
+        Data parallelism is opt-in: pass `process_group=` (a torch.distributed group) or `data_parallel=True` (the
+        default group).  An initialised default group alone does NOT switch it on.  When on, rank 0's parameters
+        (and Adam moments) are broadcast at construction, as DistributedDataParallel does, so replicas start
+        identical whatever each rank's initialisation was; every rank must then call step() the same number of
+        times (each step all-reduces: see distributed.shard_units for equal-length shards)."""
         if pt_task is None:
             pt_task = "zerons" if isinstance(model, Pretext_CNN) else "clmr"
         if pt_task not in ("zerons", "clmr"):
@@ -174,16 +203,27 @@ class PretextTrainer:
         self.pg = process_group
         self.world = 1
         self.rank = 0
-        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        if data_parallel is None:
+            data_parallel = process_group is not None
+        if data_parallel:
+            if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+                raise RuntimeError("PretextTrainer(data_parallel=True): torch.distributed is not initialised "
+                                   "(zeronotesamba_amd.distributed.init_from_env)")
             self.world = torch.distributed.get_world_size(process_group)
             self.rank = torch.distributed.get_rank(process_group)
         self._flatten()
+        if self.world > 1:
+            self.broadcast_state()
 
     # ------------------------------------------------------------------ flat buffers
     def _flatten(self) -> None:
         m = self.model
         dev = next(m.parameters()).device
         _ops.require_device(next(m.parameters()), "model parameters")
+        if any(p.device != dev for p in m.parameters()):
+            raise RuntimeError("PretextTrainer: every parameter must live on ONE device (the fused step runs both "
+                               "branches in one launch per layer); the reference's branch-per-device placement "
+                               "(pretext.py:199-200) is served by the module path, pretext.train_epoch")
         # backward order: fc1, cv8 .. cv1; inside a layer: anchor w, b, postve w, b
         branches = (("anchor", m.anchor), ("postve", m.postve)) if self.pt_task == "zerons" else (("model", m),)
         self.nbr = len(branches)
@@ -223,6 +263,14 @@ class PretextTrainer:
         self.buckets = make_buckets([(n, *self.layer_slices[n]) for n in names], _BUCKET_MIN_FLOATS)
         self.reducer = GradBucketReducer(self.flat_g, self.buckets, self.pg) if self.world > 1 else None
 
+    def broadcast_state(self, src: int = 0) -> None:
+        """Make every replica's parameters, Adam moments and step counter equal to rank `src`'s (construction, and
+        after loading a checkpoint on one rank only)."""
+        from .distributed import broadcast_tensors
+        sc = torch.tensor([self.step_count], dtype=torch.int64, device=self.flat_p.device)
+        broadcast_tensors((self.flat_p, self.flat_m, self.flat_v, sc), src=src, group=self.pg)
+        self.step_count = int(sc.item())
+
     def _check_flat(self) -> None:
         for p, ptr in self._views:
             if p.data_ptr() != ptr:
@@ -261,6 +309,11 @@ class PretextTrainer:
         T = x.shape[-1]
         if B > self.batch_len:
             raise IndexError(f"PretextTrainer: {B} rows > batch_len={self.batch_len}")
+        _ops.same_device(self.flat_p, (x,), "PretextTrainer.step")
+        with _ops.on_device(x):
+            return self._step(x, B, T, update)
+
+    def _step(self, x: torch.Tensor, B: int, T: int, update: bool) -> torch.Tensor:
         drop_p = self._drop_p()
         inv_keep = 1.0 / (1.0 - drop_p)
         seed = self._next_seed()
@@ -268,10 +321,7 @@ class PretextTrainer:
         emb, acts, argm = _ops.stack_forward(x, self.P, Bs, drop_p, seed, save=True)
         out3 = torch.empty(3, dtype=torch.float32, device=x.device)
         demb = torch.empty_like(emb)
-        rc = _lib.lib().zns_ntxent_f32(emb.data_ptr(), emb[B:].data_ptr(), B, T, self.batch_len,
-                                       float(self.temperature), out3.data_ptr(), demb.data_ptr(),
-                                       demb[B:].data_ptr(), 1.0, _ops.stream_ptr())
-        _lib.check(rc, "zns_ntxent_f32")
+        _ops.ntxent(emb[:B], emb[B:], B, T, self.batch_len, self.temperature, out3, demb[:B], demb[B:])
         hook = self.reducer.layer_done if self.reducer is not None else None
         _ops.stack_backward(x, self.P, Bs, acts, argm, emb, demb, None, inv_keep, self.G, accumulate=False,
                             after_layer=hook)
@@ -282,7 +332,7 @@ class PretextTrainer:
             rc = _lib.lib().zns_adam_step_f32(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
                                               self.flat_v.data_ptr(), self.n_flat, self.lr, self.betas[0],
                                               self.betas[1], self.eps, self.step_count, 1.0 / self.world,
-                                              _ops.stream_ptr())
+                                              _ops.stream_ptr(x.device))
             _lib.check(rc, "zns_adam_step_f32")
         return out3
 
@@ -290,11 +340,10 @@ class PretextTrainer:
     def evaluate(self, x: torch.Tensor) -> torch.Tensor:
         B = x.shape[0] // 2
         T = x.shape[-1]
+        _ops.same_device(self.flat_p, (x,), "PretextTrainer.evaluate")
         emb, _, _ = _ops.stack_forward(x, self.P, 2 * B // self.nbr, 0.0, 0, save=False)
         out3 = torch.empty(3, dtype=torch.float32, device=x.device)
-        rc = _lib.lib().zns_ntxent_f32(emb.data_ptr(), emb[B:].data_ptr(), B, T, self.batch_len,
-                                       float(self.temperature), out3.data_ptr(), None, None, 1.0, _ops.stream_ptr())
-        _lib.check(rc, "zns_ntxent_f32")
+        _ops.ntxent(emb[:B], emb[B:], B, T, self.batch_len, self.temperature, out3, None, None)
         return out3
 
     def train_epoch(self, loader: Iterable) -> Tuple[float, float, float]:
@@ -328,8 +377,10 @@ def mix_stems(stems: Dict[str, Any], device=None) -> Tuple[torch.Tensor, torch.T
     if any(o.numel() != n for o in others) or pos.numel() != n:
         raise ValueError("all stems must have the same length")
     anchor = torch.empty(n, dtype=torch.float32, device=pos.device)
-    rc = _lib.lib().zns_stem_mix_f32(_lib.ptr_array([o.data_ptr() for o in others]), len(others), n,
-                                     anchor.data_ptr(), _ops.stream_ptr())
+    _ops.same_device(pos, others, "mix_stems")
+    with _ops.on_device(pos):
+        rc = _lib.lib().zns_stem_mix_f32(_lib.ptr_array([o.data_ptr() for o in others]), len(others), n,
+                                         anchor.data_ptr(), _ops.stream_ptr(pos.device))
     _lib.check(rc, "zns_stem_mix_f32")
     anchor._zns_keep = others      # sources must outlive the enqueued kernel
     return anchor, pos

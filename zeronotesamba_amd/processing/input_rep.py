@@ -32,8 +32,9 @@ def generate_XQT_batch(signals: torch.Tensor, sample_rate: int, mode: str) -> to
     T = L.zns_xqt_frames(n)
     out = torch.empty((n_clips, 96, T), dtype=torch.float32, device=x.device)
     ws = _ops.workspace(L.zns_xqt_workspace_bytes(n_clips, n, _MODES[mode]), x.device, slot=1)
-    rc = L.zns_xqt_f32(x.data_ptr(), n_clips, n, int(sample_rate), _MODES[mode], out.data_ptr(), ws.data_ptr(),
-                       ws.numel(), _ops.stream_ptr())
+    with _ops.on_device(x):       # the FIR bank is cached per device
+        rc = L.zns_xqt_f32(x.data_ptr(), n_clips, n, int(sample_rate), _MODES[mode], out.data_ptr(), ws.data_ptr(),
+                           ws.numel(), _ops.stream_ptr(x.device))
     if rc == _lib.ZNS_ERR_MODE:
         raise Exception("Mode can only be vqt or cqt!")
     _lib.check(rc, "zns_xqt_f32")

@@ -48,9 +48,11 @@ def gate_counts(anchor: torch.Tensor, positive: torch.Tensor, starts: Optional[S
     counts = torch.empty(n_cand, dtype=torch.int32, device=dev)
     ra = torch.empty((n_cand, n_frames), dtype=torch.float32, device=dev) if want_rms else None
     rp = torch.empty((n_cand, n_frames), dtype=torch.float32, device=dev) if want_rms else None
-    rc = L.zns_rms_gate_f32(anchor.data_ptr(), positive.data_ptr(), st.data_ptr(), n_cand, int(n_samples),
-                            ra.data_ptr() if want_rms else None, rp.data_ptr() if want_rms else None,
-                            counts.data_ptr(), _ops.stream_ptr())
+    _ops.same_device(anchor, (positive,), "RMS gate")
+    with _ops.on_device(anchor):
+        rc = L.zns_rms_gate_f32(anchor.data_ptr(), positive.data_ptr(), st.data_ptr(), n_cand, int(n_samples),
+                                ra.data_ptr() if want_rms else None, rp.data_ptr() if want_rms else None,
+                                counts.data_ptr(), _ops.stream_ptr(dev))
     _lib.check(rc, "zns_rms_gate_f32")
     counts._zns_keep = st          # the start table must outlive the enqueued kernel
     return counts, n_frames, ra, rp
