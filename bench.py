@@ -9,10 +9,17 @@ Prints ONE JSON line on rank 0.  `value` = pretext steps/sec summed over ranks (
 16-item batch: weak scaling, no data-path collective, gradient all-reduce over RCCL).  `roofline` is for the
 dominant kernel (see DESIGN.md "Measurement"), timed with HIP events recorded by the library on the launch
 stream; `cpu_baseline` is the CPU oracle timed on this box's host cores (rank 0, N=1 only).
+
+After the timed region (never inside `ms_per_step`) rank 0 at N=1 also measures, into `config`:
+  module_path_ms_per_step   the literal drop-in path: Pretext_CNN autograd + NTXent + torch.optim.Adam (pretext.py:475-492)
+  xqt                       BASELINE configs[1]: generate_XQT on 32 and on 4096 resident 10 s clips
+  finetune                  BASELINE configs[3]: Down_CNN + BCE + Adam on one 30 s clip, T = 1876 (epochs.py:48-63)
+and at N>1: comm_exposed_ms (step time with minus without the gradient all-reduce) and allreduce_bytes.
 """
 import argparse
 import ctypes
 import json
+import math
 import os
 import sys
 import time
@@ -34,41 +41,102 @@ LAYER_GEOM = {"cv2": (64, 64, 7, 13, 96), "cv3": (64, 128, 5, 15, 32), "cv4": (1
               "cv5": (128, 256, 3, 19, 8), "cv6": (256, 256, 5, 21, 8)}   # cin, cout, kh, kw, H
 
 
-def spectral_flop(layer: str, useful: bool) -> float:
-    """FLOP of ONE pass (fwd, dgrad or wgrad) of `layer` in the frequency-domain form, both branches, B=16:
-    32 frequencies x 3 real GEMMs (Karatsuba) of cout x (cin*kh) per window position (executed); frequency slot 0
-    (DC + Nyquist, both real) needs only two of its three (useful).  Tile padding is not counted."""
+def spectral_flop(layer: str, useful: bool, frames: int = T, samples: int = 2 * B) -> float:
+    """FLOP of ONE pass (fwd, dgrad or wgrad) of `layer` in the frequency-domain form over `samples` spectrograms of
+    `frames` columns (default: both branches, B=16, T=512): 32 frequencies x 3 real GEMMs (Karatsuba) of
+    cout x (cin*kh) per window position (executed); frequency slot 0 (DC + Nyquist, both real) needs only two of its
+    three (useful).  Rows longer than 12 windows run as NS segments of NB windows.  Tile padding is not counted."""
     cin, cout, kh, kw, H = LAYER_GEOM[layer]
     V = 64 - kw + 1
-    P = H * (-(-T // V))
+    nbt = -(-frames // V)
+    ns = -(-nbt // 12)
+    nb = -(-nbt // ns)
+    P = H * nb * ns
     slots = (31 * 3 + 2) if useful else 32 * 3
-    return 2.0 * slots * cout * cin * kh * P * (2 * B)
+    return 2.0 * slots * cout * cin * kh * P * samples
+
+
+def exec_flop(frames: int, samples: int) -> float:
+    """MFMA FLOP executed by one training step: cv2..cv6 in the frequency domain (3 passes), cv7/cv8 direct (3 passes)."""
+    return (3 * sum(spectral_flop(l, False, frames, samples) for l in LAYER_GEOM)
+            + 3 * 2 * samples * (MACS["cv7"] + MACS["cv8"]) * frames / 512.0)
 
 
 # MFMA FLOP actually executed per step: cv2..cv6 in the frequency domain (3 passes), cv7/cv8 direct (3 passes)
-EXEC_FLOP = 3 * sum(spectral_flop(l, False) for l in LAYER_GEOM) + 3 * 2 * 2 * B * (MACS["cv7"] + MACS["cv8"])
+EXEC_FLOP = exec_flop(T, 2 * B)
 # dominant kernel (profiles/): the frequency-domain forward GEMM-conv of cv4 (conv_core<128,128,1x9 taps, 12-wave HET layout>)
 PROBE = dict(kind=0, cin=128, cout=128, kh=9, name="conv_core<spectral cv4 forward: 96 real 128x1152 GEMM-convs per sample, 9 row taps>",
              flop=spectral_flop("cv4", True),
-             # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/r01h_pmc_summary.csv):
-             # FETCH_SIZE 608 304 KB x 2 (gfx950 counts the 128-B requests of 16-byte loads as 64 B) + WRITE_SIZE 540 672 KB
-             traffic=(2 * 608304 + 540672) * 1024.0)
+             # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/r01h_pmc_summary.csv), NOT measured by
+             # this run: FETCH_SIZE 608 304 KB x 2 (gfx950 counts the 128-B requests of 16-byte loads as 64 B) +
+             # WRITE_SIZE 540 672 KB
+             traffic=(2 * 608304 + 540672) * 1024.0,
+             traffic_source="constant from separate rocprofv3 --pmc passes (profiles/), 2 x FETCH_SIZE + WRITE_SIZE; not measured by this run")
 
 
-def synth_batch(seed: int, device) -> torch.Tensor:
+def _lowbias32(x):
+    import numpy as np
+    x = x.astype(np.uint32, copy=True)
+    with np.errstate(over="ignore"):
+        x ^= x >> np.uint32(16)
+        x *= np.uint32(0x7FEB352D)
+        x ^= x >> np.uint32(15)
+        x *= np.uint32(0x846CA68B)
+        x ^= x >> np.uint32(16)
+    return x
+
+
+def uniform_pm1(seed: int, n: int):
+    """Exactly reproducible U(-1, 1) float32 stream from an integer hash: the same closed-form generator the golden
+    fixtures use (tests/golden/make_golden.py via the oracle), re-implemented here so bench.py's product path imports
+    nothing from oracle/."""
+    import numpy as np
+    with np.errstate(over="ignore"):
+        h = _lowbias32((np.arange(n, dtype=np.uint64) & np.uint64(0xFFFFFFFF)).astype(np.uint32) * np.uint32(0x9E3779B1)
+                       ^ np.uint32(seed & 0xFFFFFFFF))
+    return ((h >> np.uint32(8)).astype(np.float64) / 8388608.0 - 1.0).astype(np.float32)
+
+
+def synth_state_dict(model: torch.nn.Module, seed: int = 5, gain: float = 2.0, head_gain: float = 2.0, head_bias: float = -5.0):
+    """Closed-form random init that keeps the embeddings from collapsing: weights U(-b, b) with
+    b = gain / sqrt(fan_in), biases U(-0.05, 0.05); the sigmoid head gets a negative bias and a larger gain so the
+    pulse embedding is sparse (mean ~0.08) instead of a constant ~0.7 whose cosine to anything is 1."""
+    import numpy as np
+    sd = {}
+    for k, (name, ref) in enumerate(model.state_dict().items()):
+        shape = tuple(ref.shape)
+        n = int(np.prod(shape))
+        u = uniform_pm1(seed * 1000 + k, n)
+        if name.endswith("bias"):
+            v = u * np.float32(0.05)
+            if ".fc1." in name or name.startswith("fc1."):
+                v = v + np.float32(head_bias)
+        else:
+            v = u * np.float32(gain / np.sqrt(int(np.prod(shape[1:]))))
+            if ".fc1." in name or name.startswith("fc1."):
+                v = v * np.float32(head_gain)
+        sd[name] = torch.from_numpy(v.reshape(shape).copy())
+    return sd
+
+
+def synth_batch(seed: int, device, frames: int = None) -> torch.Tensor:
+    """One pretext batch as pretext.py:308-318 builds it: 16 DISTINCT time shifts of ONE clip.  The clip is a synthetic
+    VQT-like bank row (log-magnitudes in [-20.72, 3]); the positive stem shares 70 % of the anchor's content (drums vs the
+    rest of the same music).  [B, 2, 96, T]."""
+    T_ = T if frames is None else frames
     g = torch.Generator(device="cpu").manual_seed(seed)
-    x = torch.randn((B, 2, 96, T), generator=g) * 3.0 - 6.0
+    base = torch.randn((96, 2 * T_), generator=g) * 3.0 - 6.0
+    other = torch.randn((96, 2 * T_), generator=g) * 3.0 - 6.0
+    pos = 0.7 * base + 0.3 * other
+    starts = torch.randperm(T_, generator=g)[:B].tolist()
+    x = torch.stack([torch.stack([base[:, s:s + T_], pos[:, s:s + T_]]) for s in starts])
     return x.clamp_(-20.72, 3.0).to(device)
 
 
 def build_model(device):
     from zeronotesamba_amd.models.models import Pretext_CNN
-    torch.manual_seed(0)
     m = Pretext_CNN()
-    with torch.no_grad():
-        for name, p in m.named_parameters():
-            if name.endswith("weight"):
-                p.mul_(2.0)   # keep the sigmoid embeddings from collapsing to a constant (SURVEY.md section 7)
+    m.load_state_dict(synth_state_dict(m))
     return m.to(device)
 
 
@@ -92,7 +160,7 @@ def cpu_baseline(max_seconds: float = 30.0):
     torch.set_num_threads(cores)
     sd = {k: v.clone() for k, v in build_model("cpu").state_dict().items()}
     op = step_ref.OracleParams(sd, LR)
-    batch = synth_batch(0, "cpu")
+    batch = synth_batch(100, "cpu")
     step_ref.pretext_step(op, batch[..., :64].contiguous(), B, TAU, drop_seed=1)   # warm-up (oneDNN primitives, threads)
     times = []
     while len(times) < 3 and (sum(times) < max_seconds * 0.6 or not times):
@@ -106,12 +174,138 @@ def cpu_baseline(max_seconds: float = 30.0):
             "s_per_step": per}
 
 
+def _timed(fn, iters: int, warm: int = 2) -> float:
+    """ms per call of fn() on the current stream, wall clock bracketed by synchronize (inputs already resident)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+def measure_module_path(dev, iters: int = 10) -> dict:
+    """The literal drop-in path INTEGRATION.md section 1 gives a user who only switches imports: the reference's own
+    step structure (pretext.py:475-492) -- Pretext_CNN under autograd, NTXent, stock torch.optim.Adam over the 36
+    parameter tensors -- on the same model, batch and dropout as the fused PretextTrainer the headline times."""
+    from zeronotesamba_amd.models.loss_functions import NTXent
+    model = build_model(dev).train()
+    crit = NTXent(B, TAU)
+    opt = torch.optim.Adam(model.parameters(), lr=LR)
+    batch = synth_batch(100, dev)
+    anchors, postves = batch[:, 0:1].contiguous(), batch[:, 1:2].contiguous()
+    torch.manual_seed(0)
+
+    def step():
+        opt.zero_grad()
+        a, p = model(anchors, postves)
+        loss, _, _ = crit(a, p)          # includes the reference's device->host copy of the two cosine means
+        loss.backward()
+        opt.step()
+
+    return {"module_path_ms_per_step": _timed(step, iters, 3)}
+
+
+XQT_SAMPLES = 160000                     # 10 s at 16 kHz (BASELINE configs[1])
+XQT_BYTES_PER_CLIP = XQT_SAMPLES * 4 + 96 * (1 + XQT_SAMPLES // 256) * 4      # SURVEY 8(d): 640 KB in + 240 KB out
+XQT_TAPS_PER_CLIP = 63 * sum(-(-XQT_SAMPLES // (1 << i)) for i in range(1, 8))   # decimation: 63 taps per pyramid sample
+XQT_FILTER_FLOP_PER_CLIP = 2 * 2 * 12 * (1 + XQT_SAMPLES // 256) * (128 * 4 + 64 + 32 + 32 + 16)   # complex FIR bank, VQT
+F64_TAP_CEILING = 12.7e12                # taps/s/chip: fma_f64 + cvt_f32_f64 + cvt_f64_f32 = 12.35 cycles per wave (tools/ubench_f64.hip)
+
+
+def measure_xqt(dev, cpu: bool) -> dict:
+    """BASELINE configs[1]: generate_XQT on 32 resident clips and on a bandwidth-saturating 4096; the two
+    stages are also timed alone.  Bounds: the whole transform against the 8 TB/s HBM roofline (algorithmic bytes), the
+    bit-exact decimation against its float64 instruction-issue ceiling, the filter bank against the fp32 FMA peak."""
+    from zeronotesamba_amd.processing.input_rep import generate_XQT_batch
+    out = {}
+    for n_clips, iters in ((32, 50), (4096, 3)):
+        g = torch.Generator(device="cpu").manual_seed(1234)
+        y = (0.1 * torch.randn((min(n_clips, 64), XQT_SAMPLES), generator=g)).to(dev)
+        if n_clips > y.shape[0]:
+            y = y.repeat(n_clips // y.shape[0], 1).contiguous()
+        res = torch.empty((n_clips, 96, 1 + XQT_SAMPLES // 256), dtype=torch.float32, device=dev)
+        ms = _timed(lambda: generate_XQT_batch(y, SR, "vqt", out=res), iters)
+        ms_pyr = _timed(lambda: generate_XQT_batch(y, SR, "vqt", out=res, stages=1), iters)
+        ms_fir = _timed(lambda: generate_XQT_batch(y, SR, "vqt", out=res, stages=2), iters)
+        gbps = n_clips * XQT_BYTES_PER_CLIP / (ms * 1e-3) / 1e9
+        out[f"clips_{n_clips}"] = {
+            "ms": ms, "clips_per_s": n_clips / (ms * 1e-3), "algorithmic_GBps": gbps, "frac_of_8TBps": gbps / 8000.0,
+            "pyramid_ms": ms_pyr, "pyramid_frac_of_f64_issue_ceiling": n_clips * XQT_TAPS_PER_CLIP / (ms_pyr * 1e-3) / F64_TAP_CEILING,
+            "filter_ms": ms_fir, "filter_frac_of_fp32_peak": n_clips * XQT_FILTER_FLOP_PER_CLIP / (ms_fir * 1e-3) / (FP32_MFMA_PEAK_TFLOPS * 1e12)}
+        del y, res
+    out["bound"] = ("hbm by SURVEY 8(d); in practice the bit-exact resampy accumulation (one float32 rounding per tap = 3 "
+                    "half-rate float64-path instructions) bounds the pyramid at 12.7e12 taps/s, see DESIGN.md section 5")
+    if cpu:
+        import numpy as np
+        from oracle import vqt_ref
+        rng = np.random.default_rng(1234)
+        yc = (0.1 * rng.standard_normal((3, XQT_SAMPLES))).astype(np.float32)
+        vqt_ref.generate_XQT(yc[0], SR, "vqt")                       # builds and caches the filter bank
+        t0 = time.perf_counter()
+        for i in (1, 2):
+            vqt_ref.generate_XQT(yc[i], SR, "vqt")
+        out["cpu_oracle_s_per_clip"] = (time.perf_counter() - t0) / 2
+        out["cpu_oracle_sample"] = "2 clips, numpy restatement of librosa/resampy, 1 process, per-clip loop as the reference"
+    return out
+
+
+FT_T = 1876                              # 30 s Ballroom-like clip (SURVEY 8d, config 4)
+
+
+def measure_finetune(dev, cpu: bool, iters: int = 10) -> dict:
+    """BASELINE configs[3] (epochs.py:48-63 through loader.load_models("pretrained", "finetune")): batch of one 30 s clip,
+    Down_CNN(max) forward -> BCELoss vs a 120-BPM pulse mask -> backward -> Adam(lr = 0.5 * 1e-5 * 10e-2)."""
+    from zeronotesamba_amd.loader import load_models
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        crit, opt, model = load_models("pretrained", "finetune", 1e-5, state_dict=build_model("cpu").state_dict(),
+                                       device=str(dev))
+    model.train()
+    g = torch.Generator(device="cpu").manual_seed(1)
+    vqt = (torch.randn((2, 96, FT_T), generator=g) * 3.0 - 6.0).clamp_(-20.72, 3.0)
+    msk = torch.zeros((1, FT_T))
+    msk[0, 5::31] = 1.0
+    msk[0, 4::31] = 0.5
+    msk[0, 6::31] = 0.5
+    v1, v2, m = vqt[0].reshape(1, 1, 96, FT_T).to(dev), vqt[1].reshape(1, 1, 96, FT_T).to(dev), msk.to(dev)
+    torch.manual_seed(0)
+
+    def step():
+        opt.zero_grad()
+        loss = crit(model(v1, v2), m)
+        loss.backward()
+        opt.step()
+
+    ms = _timed(step, iters, 3)
+    flop = exec_flop(FT_T, 2)
+    out = {"frames": FT_T, "ms_per_step": ms, "steps_per_s": 1e3 / ms,
+           "direct_conv_tflop_per_step": 2 * 2 * (3 * sum(MACS.values()) - MACS["cv1"]) * FT_T / 512.0 / 1e12,
+           "executed_mfma_tflop_per_step": flop / 1e12,
+           "executed_frac_of_fp32_mfma_peak": flop / (ms * 1e-3) / (FP32_MFMA_PEAK_TFLOPS * 1e12)}
+    if cpu:
+        from oracle import step_ref
+        torch.set_num_threads(host_cores())
+        sd = {"pretext." + k: v.clone() for k, v in build_model("cpu").state_dict().items()}
+        op = step_ref.OracleParams(sd, 5e-7)
+        step_ref.finetune_step(op, vqt[..., :64].contiguous(), msk[0, :64], drop_seed=1)     # warm-up
+        t0 = time.perf_counter()
+        step_ref.finetune_step(op, vqt, msk[0], drop_seed=2)
+        out["cpu_oracle_s_per_step"] = time.perf_counter() - t0
+        out["cpu_oracle_sample"] = f"1 full fine-tune step after a T=64 warm-up; {host_cores()} threads"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the module-path / generate_XQT / fine-tune measurements")
     args = ap.parse_args()
 
     from zeronotesamba_amd import _lib
@@ -133,7 +327,7 @@ def main():
     dev = torch.device("cuda", local)
 
     model = build_model(dev)
-    trainer = PretextTrainer(model, batch_len=B, temperature=TAU, lr=LR, seed=1234, train=True)
+    trainer = PretextTrainer(model, batch_len=B, temperature=TAU, lr=LR, seed=1234, train=True, data_parallel=world > 1)
     x = trainer.stack_inputs(synth_batch(100 + rank, dev))   # resident in HBM before the timed region
 
     def barrier():
@@ -172,6 +366,24 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    comm = {}
+    if world > 1:
+        # exposed communication: the same K steps with the gradient all-reduce switched off (replicas drift apart, which
+        # is irrelevant after the timed region); exposed = with - without.  Every rank runs it: same barriers.
+        reducer, trainer.reducer = trainer.reducer, None
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(K):
+            trainer.step(x)
+        barrier()
+        dt_nc = time.perf_counter() - t1
+        trainer.reducer = reducer
+        tnc = torch.tensor([dt_nc], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tnc, op=torch.distributed.ReduceOp.MAX)
+        dt_nc = float(tnc.item())
+        comm = {"comm_exposed_ms": (dt - dt_nc) / K * 1e3, "ms_per_step_without_allreduce": dt_nc / K * 1e3,
+                "allreduce_bytes": trainer.n_flat * 4, "allreduce_buckets": len(trainer.buckets)}
+
     if rank == 0:
         kms = [a.elapsed_time(b) for a, b in zip(ev0[:min(K, nprobe)], ev1[:min(K, nprobe)])]
         kavg = sum(kms) / max(len(kms), 1)
@@ -200,13 +412,28 @@ def main():
                        "direct_conv_equivalent_tflops_per_gpu": STEP_FLOP * K / dt / 1e12,
                        "executed_mfma_tflop_per_step": EXEC_FLOP / 1e12,
                        "executed_frac_of_fp32_mfma_peak": (EXEC_FLOP * K / dt) / (FP32_MFMA_PEAK_TFLOPS * 1e12),
-                       "last_loss": float(out[0].item())},
+                       "last_loss": float(out[0].item()), "ln_batch": math.log(B),
+                       "mean_cos_anchor_positive": float(out[1].item()), "mean_cos_anchor_negative": float(out[2].item()),
+                       "init": "closed-form hash init (the golden fixtures' generator), sparse sigmoid head; independent "
+                               "anchor / positive branches, so NT-Xent starts near ln(batch) by construction -- the "
+                               "cosines (not 1.0000) show the embeddings are not collapsed",
+                       **comm},
             "roofline": {"bound": "mfma", "kernel": PROBE["name"], "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": PROBE["traffic"],
-                         "kernel_ms": kavg, "launches_timed": len(kms)},
+                         "traffic_source": PROBE["traffic_source"], "kernel_ms": kavg, "launches_timed": len(kms)},
         }
+        if world == 1 and not args.no_extras:
+            del trainer, model
+            torch.cuda.empty_cache()
+            cpu = not args.no_cpu_baseline
+            res["config"].update(measure_module_path(dev))
+            res["config"]["module_path_vs_fused"] = res["config"]["module_path_ms_per_step"] / res["ms_per_step"]
+            res["config"]["xqt"] = measure_xqt(dev, cpu)
+            res["config"]["finetune"] = measure_finetune(dev, cpu)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
+            res["cpu_baseline"]["sample"] += ("; GPU-utilisation samplers see ~0 % on this command: the timed GPU region is "
+                                              "under a second inside tens of seconds of CPU baseline")
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

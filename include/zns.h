@@ -151,6 +151,10 @@ int zns_xqt_frames(int n_samples);
 int zns_xqt_host_bank(int mode, int* n_fft8, float* fir, size_t fir_floats, double* taps63);
 int zns_xqt_f32(const float* wav, int n_clips, int n_samples, int sample_rate, int mode,
                 float* out, void* ws, size_t ws_bytes, void* stream);
+/* The same, one stage at a time (measurement and tests): stages = 1 builds the decimation pyramid in `ws`, 2 applies
+ * the filter bank to the pyramid already in `ws`, 3 = both = zns_xqt_f32. */
+int zns_xqt_stages_f32(const float* wav, int n_clips, int n_samples, int sample_rate, int mode,
+                       float* out, void* ws, size_t ws_bytes, int stages, void* stream);
 
 /* ------------------------------------------------------------------ shift batching (pretext.py:285-292,308-321)
  * bank: [n_bank, 2, 96, bank_T]; for item i of the batch: out[i] = bank[clip[i], :, :, start[i]:start[i]+T]

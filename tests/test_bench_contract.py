@@ -43,6 +43,19 @@ def test_bench_line_has_every_contract_field():
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["launches_timed"] == 2
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.3 < rf["frac"] < 1.0
     assert 5.0 < r["value"] < 200.0
+    # the other BASELINE configs ride in `config`, measured after the timed region
+    c = r["config"]
+    assert c["module_path_ms_per_step"] > 0 and 0.8 < c["module_path_vs_fused"] < 3.0
+    for n in ("clips_32", "clips_4096"):
+        x = c["xqt"][n]
+        for k in ("ms", "clips_per_s", "algorithmic_GBps", "frac_of_8TBps", "pyramid_ms", "filter_ms",
+                  "pyramid_frac_of_f64_issue_ceiling", "filter_frac_of_fp32_peak"):
+            assert x[k] > 0, (n, k)
+        assert x["pyramid_frac_of_f64_issue_ceiling"] < 1.0 and x["frac_of_8TBps"] < 1.0
+    ft = c["finetune"]
+    assert ft["frames"] == 1876 and ft["ms_per_step"] > 0 and 0 < ft["executed_frac_of_fp32_mfma_peak"] < 1.0
+    # the benchmarked embeddings are not collapsed to a constant (cosines would read 1.0000)
+    assert c["mean_cos_anchor_positive"] < 0.9 and abs(c["last_loss"] - c["ln_batch"]) < 0.5
 
 
 @pytest.mark.gpu
@@ -67,5 +80,8 @@ def test_bench_two_ranks_dry_run_on_one_gpu():
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["steps"] == 2 and r["scaling"] == "weak"
     assert r["config"]["global_batch"] == 32 and r["config"]["parallelism"] == "dp2"
+    # what SCALE needs to read the overlap from: step time with minus without the gradient all-reduce, and its size
+    assert "comm_exposed_ms" in r["config"] and r["config"]["allreduce_bytes"] >= 26819202 * 4
+    assert r["config"]["ms_per_step_without_allreduce"] > 0 and r["config"]["allreduce_buckets"] >= 3
     assert "cpu_baseline" not in r
     assert abs(r["value"] - 2 * 1000.0 / r["ms_per_step"]) < 1e-6 * r["value"]      # whole-job steps/s

@@ -48,6 +48,7 @@ SIGNATURES = {
     "zns_xqt_host_bank": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_size_t,
                                     C.POINTER(C.c_double)]),
     "zns_xqt_f32": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp, C.c_size_t, c_fp]),
+    "zns_xqt_stages_f32": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp, C.c_size_t, C.c_int, c_fp]),
     "zns_shift_gather_f32": (C.c_int, [c_fp, C.c_int, c_fp, c_fp, C.c_int, C.c_int, c_fp, c_fp]),
     "zns_stem_mix_f32": (C.c_int, [c_fp, C.c_int, C.c_longlong, c_fp, c_fp]),
     "zns_rms_frames": (C.c_int, [C.c_int]),

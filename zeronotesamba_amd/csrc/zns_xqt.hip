@@ -446,6 +446,11 @@ size_t zns_xqt_workspace_bytes(int n_clips, int n_samples, int mode) {
 
 int zns_xqt_f32(const float* wav, int n_clips, int n_samples, int sample_rate, int mode, float* out, void* ws,
                 size_t ws_bytes, void* stream) {
+    return zns_xqt_stages_f32(wav, n_clips, n_samples, sample_rate, mode, out, ws, ws_bytes, 3, stream);
+}
+
+int zns_xqt_stages_f32(const float* wav, int n_clips, int n_samples, int sample_rate, int mode, float* out, void* ws,
+                       size_t ws_bytes, int stages, void* stream) {
     if (mode != ZNS_MODE_VQT && mode != ZNS_MODE_CQT) {
         set_error("Mode can only be vqt or cqt!");
         return ZNS_ERR_MODE;
@@ -482,10 +487,11 @@ int zns_xqt_f32(const float* wav, int n_clips, int n_samples, int sample_rate, i
             L.stride[i] = (long long)(((size_t)len[i] + 3) / 4 * 4);
         }
     }
+    ZNS_CHECK_ARG(stages >= 1 && stages <= 3, "xqt: stages=%d (1 pyramid, 2 filter bank, 3 both)", stages);
     // decimation pyramid: levels 1..7, grouped into chains (one launch each).  Default plan: the three big levels on
     // their own (no recomputed halo where 7/8 of the taps are), the four small ones fused (their launches are
     // latency-bound: 6.5 us each for a 32-clip batch).  ZNS_XQT_PLAN="n1,n2,.." overrides the grouping (tuning aid).
-    {
+    if (stages & 1) {
         int plan[XQ_OCT] = {1, 1, 1, 4}, nplan = 4;
         if (const char* e = getenv("ZNS_XQT_PLAN")) {
             nplan = 0;
@@ -526,6 +532,7 @@ int zns_xqt_f32(const float* wav, int n_clips, int n_samples, int sample_rate, i
             a += nlev;
         }
     }
+    if (!(stages & 2)) return ZNS_OK;
     const int n_frames = zns_xqt_frames(n_samples);
     int max_fft = 0;
     for (int i = 0; i < XQ_OCT; ++i) max_fft = std::max(max_fft, b->n_fft[i]);
