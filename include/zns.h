@@ -75,11 +75,26 @@ size_t zns_conv2d_spectrum_bytes(int nbr, int B, int T, int cin, int cout, int k
  * then as `dzspec` to zns_conv2d_dgrad_f32 -- dZ is then read and transformed once for both. */
 size_t zns_conv2d_dz_spectrum_bytes(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H);
 
+/* Packed-weight hand-off.  The MFMA kernels stream the weights in a kernel-specific order (K-stage slabs; for the
+ * frequency-domain kernels: 96 real operators per branch built from the 64-point DFT of the time taps, 5-7x the size of
+ * the weights).  By default every forward / backward-data call builds that operand itself.  A caller whose weights do
+ * not change between calls (module.eval(), val_epoch pretext.py:527-592, inference sample_script.py:46-48) packs once:
+ *   bytes = zns_conv2d_packed_bytes(geometry, transposed, &layout_id)    (0 bytes / id 0: nothing to pack)
+ *   zns_conv2d_pack_f32(geometry, transposed, w, dst, bytes, stream)
+ * and passes `wpk = dst` to zns_conv2d_fwd_f32 (transposed = 0) / zns_conv2d_dgrad_f32 (transposed = 1).  `wpk` is valid
+ * for every call whose geometry reports the SAME layout_id (the id depends on the layer, on the tile variant the
+ * dispatcher picks from T, and on zns_set_impl) -- not only for the T it was packed at. */
+size_t zns_conv2d_packed_bytes(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, int transposed,
+                               int* layout_id);
+int zns_conv2d_pack_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, int transposed,
+                        const float* const* w, float* dst, size_t dst_bytes, void* stream);
+
 int zns_conv2d_fwd_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, int pool,
                        const float* x, const float* const* w, const float* const* bias,
                        float* y, uint8_t* argmax,
                        float drop_p, uint32_t seed, int layer,
                        float* xspec /* nullable: receives the input spectrum, see zns_conv2d_spectrum_bytes */,
+                       const float* wpk /* nullable: weights packed by zns_conv2d_pack_f32(transposed = 0) */,
                        void* ws, size_t ws_bytes, void* stream);
 
 /* Backward-data of the same conv (autograd of models.py:37-70):
@@ -96,6 +111,7 @@ int zns_conv2d_dgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int k
                          const float* dz, const float* const* w, float* dx,
                          const float* x, float inv_keep, const uint8_t* prev_argmax, int prev_pool,
                          const float* dzspec /* nullable: dZ spectrum left by zns_conv2d_wgrad_f32 */,
+                         const float* wpk /* nullable: weights packed by zns_conv2d_pack_f32(transposed = 1) */,
                          void* ws, size_t ws_bytes, void* stream);
 
 /* Backward-weights: dw[br] (+)= sum_{b,h,t} dz (x) shifted x ; db[br] (+)= sum dz.

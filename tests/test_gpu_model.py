@@ -280,6 +280,72 @@ def test_finetune_step_gradients_with_replayed_decisions(red):
             assert grad_err(k, v.grad, ref) <= 1e-4, (T, k, grad_err(k, v.grad, ref))
 
 
+def test_packed_weights_are_cached_until_the_weights_change(monkeypatch):
+    """The kernel-order weight operand (frequency weights: 0.5 GB per forward over cv2..cv6 at B=16) is built once per
+    weight VERSION: repeated eval-mode calls (val_epoch pretext.py:527-592, sample_script.py:46-48) launch no pack
+    kernel after the first, any optimizer step (stock torch Adam, the fused Adam, the fused trainer) invalidates it, and
+    a stale operand is never used: outputs always equal those of a freshly built model holding the same weights."""
+    from zeronotesamba_amd import _lib
+    from zeronotesamba_amd.models.loss_functions import NTXent
+    from zeronotesamba_amd.models.models import Pretext_CNN
+    from zeronotesamba_amd.optim import Adam
+    from zeronotesamba_amd.pretext import PretextTrainer, val_epoch
+    L = _lib.lib()
+    calls = []
+    real = L.zns_conv2d_pack_f32
+    monkeypatch.setattr(L, "zns_conv2d_pack_f32", lambda *a: (calls.append(a[8]), real(*a))[1])   # a[8] = transposed
+
+    def fresh(sd):
+        m = Pretext_CNN()
+        m.load_state_dict(sd)
+        return m.to(DEV).eval()
+
+    B, T = 2, 72
+    sd = cnn_ref.synth_state_dict(3, 2.0)
+    m = fresh(sd)
+    anc, pos = cnn_ref.synth_vqt(101, (B, 1, 96, T)).to(DEV), cnn_ref.synth_vqt(102, (B, 1, 96, T)).to(DEV)
+    with torch.no_grad():
+        a1, p1 = m(anc, pos)
+        n1 = len(calls)
+        assert n1 == 7 and not any(calls)                       # cv2..cv8 forward operands, cv1 takes the weights as they are
+        a2, p2 = m(anc, pos)
+        a3 = m.anchor(cnn_ref.synth_vqt(103, (1, 1, 96, 40)).to(DEV))      # another T, lone branch: nbr = 1 operand
+        assert len(calls) == n1 + 7
+        m.anchor(cnn_ref.synth_vqt(104, (3, 1, 96, 40)).to(DEV))           # another batch size, same layout: no new pack
+        assert len(calls) == n1 + 7
+    assert torch.equal(a1, a2) and torch.equal(p1, p2)
+    crit = NTXent(B, 0.25)
+    loader = [[cnn_ref.synth_vqt(200 + i, (B, 2, 96, T))] for i in range(3)]
+    n = len(calls)
+    val_epoch(m, loader, crit, None)
+    assert len(calls) == n                                      # a whole validation epoch without a single pack launch
+    # a training step changes the weights: forward AND backward-data operands are rebuilt, results follow the new weights
+    for make_opt in (lambda ps: torch.optim.Adam(ps, lr=1e-5), lambda ps: Adam(ps, lr=1e-5)):
+        opt = make_opt(m.parameters())
+        a, p = m(anc, pos)
+        loss, _, _ = crit(a, p)
+        loss.backward()
+        opt.step()
+        n = len(calls)
+        with torch.no_grad():
+            a4, p4 = m(anc, pos)
+            assert len(calls) == n + 7
+            ar, pr = fresh({k: v.detach().cpu() for k, v in m.state_dict().items()})(anc, pos)
+        assert torch.equal(a4, ar) and torch.equal(p4, pr) and not torch.equal(a4, a1)
+    tr = PretextTrainer(m, batch_len=B, lr=1e-5, train=False)
+    x = tr.stack_inputs(loader[0][0])
+    e0 = tr.evaluate(x)
+    n = len(calls)
+    assert torch.equal(tr.evaluate(x), e0) and len(calls) == n
+    tr.step(x)
+    e1 = tr.evaluate(x)
+    assert not torch.equal(e1, e0)
+    with torch.no_grad():
+        ar, pr = fresh({k: v.detach().cpu() for k, v in m.state_dict().items()})(x[:B], x[B:])
+        a5, p5 = m(x[:B], x[B:])
+    assert torch.equal(a5, ar) and torch.equal(p5, pr)
+
+
 def test_frozen_backbone_gets_no_conv_grads():
     """loader.py:30-34: requires_grad=False on *.pretrained -> only fc1 receives gradients."""
     from zeronotesamba_amd.models.models import Down_CNN

@@ -4,7 +4,7 @@ There is deliberately NO fallback: if the shared library is missing or a call
 fails, a RuntimeError is raised.  Build it with ``python -m zeronotesamba_amd.build``
 (hipcc --offload-arch=gfx950), which is what ``__graft_entry__.build()`` does.
 """
-import ctypes as C
+import ctypes as C  # noqa: N812 (also re-exported as _lib.C for byref/c_int users)
 import os
 from typing import Optional
 
@@ -26,10 +26,12 @@ SIGNATURES = {
     "zns_conv2d_workspace_bytes": (C.c_size_t, [C.c_int] * 8),
     "zns_conv2d_spectrum_bytes": (C.c_size_t, [C.c_int] * 8),
     "zns_conv2d_dz_spectrum_bytes": (C.c_size_t, [C.c_int] * 8),
+    "zns_conv2d_packed_bytes": (C.c_size_t, [C.c_int] * 9 + [C.POINTER(C.c_int)]),
+    "zns_conv2d_pack_f32": (C.c_int, [C.c_int] * 9 + [c_pp, c_fp, C.c_size_t, c_fp]),
     "zns_conv2d_fwd_f32": (C.c_int, [C.c_int] * 9 + [c_fp, c_pp, c_pp, c_fp, c_fp, C.c_float, C.c_uint32, C.c_int,
-                                                     c_fp, c_fp, C.c_size_t, c_fp]),
+                                                     c_fp, c_fp, c_fp, C.c_size_t, c_fp]),
     "zns_conv2d_dgrad_f32": (C.c_int, [C.c_int] * 8 + [c_fp, c_pp, c_fp, c_fp, C.c_float, c_fp, C.c_int,
-                                                       c_fp, c_fp, C.c_size_t, c_fp]),
+                                                       c_fp, c_fp, c_fp, C.c_size_t, c_fp]),
     "zns_conv2d_wgrad_f32": (C.c_int, [C.c_int] * 8 + [c_fp, c_fp, c_pp, c_pp, C.c_int, c_fp, c_fp, c_fp,
                                                        C.c_size_t, c_fp]),
     "zns_head_fwd_f32": (C.c_int, [C.c_int] * 4 + [c_fp, c_pp, c_pp, c_fp, c_fp]),

@@ -93,6 +93,42 @@ def _pp(tensors: Sequence[torch.Tensor]):
     return _lib.ptr_array([t.data_ptr() for t in tensors])
 
 
+def packed_weights(li: int, transposed: bool, nbr: int, B: int, T: int, w: Sequence[torch.Tensor]) -> Optional[torch.Tensor]:
+    """The kernel-order operand of layer li's weights (zns_conv2d_pack_f32), rebuilt only when a weight tensor changed.
+
+    The frequency-domain kernels read 96 real operators per branch built from the DFT of the time taps (5-7x the weights:
+    0.5 GB per pass over the five layers); the reference's eval paths (val_epoch pretext.py:527-592, inference
+    sample_script.py:46-48) call the model many times with the SAME weights, so the operand is cached: on the first
+    branch's weight Parameter itself (it dies with the model), keyed by the library's layout id (layer, tile variant,
+    kernel family) and the tensors' addresses, validated by their autograd version counters.  Everything in this package
+    that writes parameters through a raw pointer (the fused Adam kernels) bumps those counters."""
+    name, cin, cout, kh, kw, pool = LAYERS[li]
+    L = _lib.lib()
+    lid = _lib.C.c_int(0)
+    with on_device(w[0]):
+        nbytes = L.zns_conv2d_packed_bytes(nbr, B, T, cin, cout, kh, kw, H_IN[li], int(transposed), _lib.C.byref(lid))
+        if lid.value == 0:
+            return None
+        key = (int(transposed), lid.value, nbr) + tuple(t.data_ptr() for t in w)
+        sig = tuple(t._version for t in w)
+        cache = w[0].__dict__.setdefault("_zns_pack", {})
+        hit = cache.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        buf = hit[1] if hit is not None else torch.empty(nbytes // 4, dtype=torch.float32, device=w[0].device)
+        same_device(w[0], w, name)
+        rc = L.zns_conv2d_pack_f32(nbr, B, T, cin, cout, kh, kw, H_IN[li], int(transposed), _pp(w), buf.data_ptr(),
+                                   buf.numel() * 4, stream_ptr(w[0].device))
+        _lib.check(rc, f"zns_conv2d_pack_f32[{name}]")
+        cache[key] = (sig, buf)
+    return buf
+
+
+def bump_version(t: torch.Tensor) -> None:
+    """Tell autograd (and packed_weights) that `t` -- and every view of it -- was written through its raw pointer."""
+    torch.autograd.graph.increment_version(t)
+
+
 def conv_fwd(li: int, nbr: int, B: int, T: int, x: torch.Tensor, w: Sequence[torch.Tensor],
              b: Sequence[torch.Tensor], drop_p: float, seed: int, want_argmax: bool, ws: torch.Tensor):
     name, cin, cout, kh, kw, pool = LAYERS[li]
@@ -108,11 +144,13 @@ def conv_fwd(li: int, nbr: int, B: int, T: int, x: torch.Tensor, w: Sequence[tor
         if nspec:
             spec = torch.empty(nspec // 4, dtype=torch.float32, device=x.device)
     same_device(x, (*w, *b, ws), name)
+    wpk = packed_weights(li, False, nbr, B, T, w)
     with on_device(x):
         rc = _lib.lib().zns_conv2d_fwd_f32(nbr, B, T, cin, cout, kh, kw, H, pool, x.data_ptr(), _pp(w), _pp(b),
                                            y.data_ptr(), am.data_ptr() if am is not None else None,
                                            float(drop_p), int(seed) & 0xFFFFFFFF, li,
                                            spec.data_ptr() if spec is not None else None,
+                                           wpk.data_ptr() if wpk is not None else None,
                                            ws.data_ptr(), ws.numel(), stream_ptr(x.device))
     _lib.check(rc, f"zns_conv2d_fwd_f32[{name}]")
     return y, am, spec
@@ -125,11 +163,13 @@ def conv_dgrad(li: int, nbr: int, B: int, T: int, dz: torch.Tensor, w: Sequence[
     H = H_IN[li]
     dx = torch.empty((nbr * B, cin, H * prev_pool, T), dtype=torch.float32, device=dz.device)
     same_device(dz, (*w, x, prev_argmax, dzspec, ws), name)
+    wpk = packed_weights(li, True, nbr, B, T, w)
     with on_device(dz):
         rc = _lib.lib().zns_conv2d_dgrad_f32(nbr, B, T, cin, cout, kh, kw, H, dz.data_ptr(), _pp(w), dx.data_ptr(),
                                              x.data_ptr() if x is not None else None, float(inv_keep),
                                              prev_argmax.data_ptr() if prev_argmax is not None else None, prev_pool,
                                              dzspec.data_ptr() if dzspec is not None else None,
+                                             wpk.data_ptr() if wpk is not None else None,
                                              ws.data_ptr(), ws.numel(), stream_ptr(dz.device))
     _lib.check(rc, f"zns_conv2d_dgrad_f32[{name}]")
     return dx

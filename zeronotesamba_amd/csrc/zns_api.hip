@@ -35,7 +35,7 @@ using namespace zns;
 extern "C" {
 
 const char* zns_last_error(void) { return g_err; }
-int zns_version(void) { return 103; }   // 101: dzspec_out / dzspec, 102: stem mix + RMS gate, 103: NT-Xent workspace (any batch size)
+int zns_version(void) { return 104; }   // 101: dzspec_out / dzspec, 102: stem mix + RMS gate, 103: NT-Xent workspace (any batch size), 104: packed-weight hand-off, staged xqt
 int zns_set_impl(int impl) {
     const int prev = g_impl;
     g_impl = impl;
@@ -74,9 +74,46 @@ size_t zns_conv2d_dz_spectrum_bytes(int nbr, int B, int T, int cin, int cout, in
     return (g_impl == ZNS_IMPL_AUTO && fft_wgrad_supported(a)) ? fft_dz_spectrum_bytes(a) : 0;
 }
 
+// which kernel family a (forward / backward-data) call of this geometry runs on: 0 naive, 1 cv1, 2 frequency domain, 3 direct
+static int conv_family(const ConvArgs& a, bool forward) {
+    if (g_impl == ZNS_IMPL_NAIVE) return 0;
+    if (forward && is_cv1(a) && a.pool == 1) return 1;
+    if (g_impl == ZNS_IMPL_AUTO && fft_supported(a)) return 2;
+    if (mfma_supported(a)) return 3;
+    return -1;
+}
+
+size_t zns_conv2d_packed_bytes(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, int transposed,
+                               int* layout_id) {
+    ConvArgs a{nbr, B, T, cin, cout, kh, kw, H, 1};
+    const int fam = conv_family(a, !transposed);
+    int id = 0;
+    size_t n = 0;
+    if (fam == 2) { id = fft_pack_layout(a, transposed); n = fft_pack_bytes(a, transposed); }
+    else if (fam == 3) { id = mfma_pack_layout(a, transposed); n = mfma_pack_bytes(a, transposed); }
+    if (layout_id) *layout_id = id;
+    return id ? n : 0;
+}
+
+int zns_conv2d_pack_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, int transposed,
+                        const float* const* w, float* dst, size_t dst_bytes, void* stream) {
+    ConvArgs a{nbr, B, T, cin, cout, kh, kw, H, 1};
+    int rc = check_conv(a, "conv2d_pack");
+    if (rc) return rc;
+    int id = 0;
+    const size_t need = zns_conv2d_packed_bytes(nbr, B, T, cin, cout, kh, kw, H, transposed, &id);
+    ZNS_CHECK_ARG(id != 0, "conv2d_pack: this geometry's kernels take the weights as they are (nothing to pack)");
+    if (dst == nullptr || dst_bytes < need) { set_error("conv2d_pack: destination %zu < %zu", dst_bytes, need); return ZNS_ERR_WORKSPACE; }
+    Ptr2 pw{};
+    for (int i = 0; i < nbr; ++i) pw.p[i] = w[i];
+    hipStream_t st = (hipStream_t)stream;
+    return id < 200 ? fft_pack(a, pw, transposed, dst, st) : mfma_pack(a, pw, transposed, dst, st);
+}
+
 int zns_conv2d_fwd_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, int pool, const float* x,
                        const float* const* w, const float* const* bias, float* y, uint8_t* argmax, float drop_p,
-                       uint32_t seed, int layer, float* xspec, void* ws, size_t ws_bytes, void* stream) {
+                       uint32_t seed, int layer, float* xspec, const float* wpk, void* ws, size_t ws_bytes,
+                       void* stream) {
     ConvArgs a{nbr, B, T, cin, cout, kh, kw, H, pool};
     int rc = check_conv(a, "conv2d_fwd");
     if (rc) return rc;
@@ -87,16 +124,16 @@ int zns_conv2d_fwd_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw,
     if (g_impl == ZNS_IMPL_NAIVE) return naive_fwd(a, x, pw, pb, y, argmax, drop_p, seed, layer, st);
     if (is_cv1(a) && pool == 1) return cv1_fwd(a, x, pw, pb, y, drop_p, seed, layer, st);
     if (g_impl == ZNS_IMPL_AUTO && fft_supported(a))
-        return fft_fwd(a, x, pw, pb, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
-    if (mfma_supported(a)) return mfma_fwd(a, x, pw, pb, y, argmax, drop_p, seed, layer, ws, ws_bytes, st);
+        return fft_fwd(a, x, pw, pb, y, argmax, drop_p, seed, layer, xspec, wpk, ws, ws_bytes, st);
+    if (mfma_supported(a)) return mfma_fwd(a, x, pw, pb, y, argmax, drop_p, seed, layer, wpk, ws, ws_bytes, st);
     set_error("conv2d_fwd: no gfx950 kernel instance for cin=%d cout=%d k=%dx%d H=%d", cin, cout, kh, kw, H);
     return ZNS_ERR_ARG;
 }
 
 int zns_conv2d_dgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, const float* dz,
                          const float* const* w, float* dx, const float* x, float inv_keep,
-                         const uint8_t* prev_argmax, int prev_pool, const float* dzspec, void* ws, size_t ws_bytes,
-                         void* stream) {
+                         const uint8_t* prev_argmax, int prev_pool, const float* dzspec, const float* wpk, void* ws,
+                         size_t ws_bytes, void* stream) {
     ConvArgs a{nbr, B, T, cin, cout, kh, kw, H, 1};
     int rc = check_conv(a, "conv2d_dgrad");
     if (rc) return rc;
@@ -106,8 +143,8 @@ int zns_conv2d_dgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int k
     hipStream_t st = (hipStream_t)stream;
     if (g_impl == ZNS_IMPL_NAIVE) return naive_dgrad(a, dz, pw, dx, x, inv_keep, prev_argmax, prev_pool, st);
     if (g_impl == ZNS_IMPL_AUTO && fft_supported(a))
-        return fft_dgrad(a, dz, pw, dx, x, inv_keep, prev_argmax, prev_pool, dzspec, ws, ws_bytes, st);
-    if (mfma_supported(a)) return mfma_dgrad(a, dz, pw, dx, x, inv_keep, prev_argmax, prev_pool, ws, ws_bytes, st);
+        return fft_dgrad(a, dz, pw, dx, x, inv_keep, prev_argmax, prev_pool, dzspec, wpk, ws, ws_bytes, st);
+    if (mfma_supported(a)) return mfma_dgrad(a, dz, pw, dx, x, inv_keep, prev_argmax, prev_pool, wpk, ws, ws_bytes, st);
     set_error("conv2d_dgrad: no gfx950 kernel instance for cin=%d cout=%d k=%dx%d H=%d", cin, cout, kh, kw, H);
     return ZNS_ERR_ARG;
 }

@@ -20,6 +20,8 @@
 // i.e. 3*32 real MACs per window position instead of V*kw: 6.8x (cv2) .. 9.4x (cv6) fewer than the direct form.
 // Spectra live in the workspace as S[sample][slot = 3 f + t][C][P], P = H*NB, planes t = (re, im, re +/- im);
 // frequency slot 0 carries the two real bins (DC in t = 0, Nyquist in t = 1, t = 2 unused).
+#include <type_traits>
+
 #include "zns_conv_core.h"
 #include "zns_fft64.h"
 
@@ -651,22 +653,33 @@ static int set_lds_fw(void (*kern)(WgArgs)) {
     return ZNS_OK;
 }
 
-// S_in [nb*FF][CIN'][P] -> S_out [nb*FF][COUT'][P] with the frequency weights of `w`
+// frequency weights of `w` in conv_core<C>'s slab order (see pack_freq_weights_kernel)
 template <class C>
-static int run_fconv(const ConvArgs& a, const FftGeom& g, Ptr2 w, int transposed, const float* s_in, float* s_out,
-                     float* wf, int probe_kind, hipStream_t st) {
-    const int cin_c = C::CIN, cout_c = C::COUT;
+static int pack_fconv(const ConvArgs& a, Ptr2 w, int transposed, float* wf, hipStream_t st) {
     const long long per_wf = (long long)C::COUT * C::CIN * C::KW;
     const long long total = per_wf * a.nbr;
     const int blocks = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(pack_freq_weights_kernel, dim3(blocks), dim3(256), 0, st, w, wf, cin_c, cout_c, C::KW, a.kw,
+    hipLaunchKernelGGL(pack_freq_weights_kernel, dim3(blocks), dim3(256), 0, st, w, wf, C::CIN, C::COUT, C::KW, a.kw,
                        C::COB, C::CK, C::MT, C::WM, transposed, per_wf, a.nbr);
     ZNS_LAUNCH_CHECK();
-    int rc = set_lds_f<C>(conv_core<C>);
+    return ZNS_OK;
+}
+
+// S_in [nb*FF][CIN'][P] -> S_out [nb*FF][COUT'][P] with the frequency weights of `w` (wpk: already packed, or NULL)
+template <class C>
+static int run_fconv(const ConvArgs& a, const FftGeom& g, Ptr2 w, int transposed, const float* s_in, float* s_out,
+                     float* wf, const float* wpk, int probe_kind, hipStream_t st) {
+    int rc = ZNS_OK;
+    if (wpk == nullptr) {
+        rc = pack_fconv<C>(a, w, transposed, wf, st);
+        if (rc) return rc;
+        wpk = wf;
+    }
+    rc = set_lds_f<C>(conv_core<C>);
     if (rc) return rc;
     CoreArgs A{};
     A.x = s_in;
-    A.wpk = wf;
+    A.wpk = wpk;
     A.dx = s_out;
     A.xmask = nullptr;
     A.inv_keep = 1.f;
@@ -689,7 +702,7 @@ static int run_fconv(const ConvArgs& a, const FftGeom& g, Ptr2 w, int transposed
 
 template <class C>
 static int fft_fwd_t(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, uint8_t* argmax, float drop_p,
-                     uint32_t seed, int layer, float* xspec, void* ws, size_t ws_bytes, hipStream_t st) {
+                     uint32_t seed, int layer, float* xspec, const float* wpk, void* ws, size_t ws_bytes, hipStream_t st) {
     const FftGeom g = geom(a);
     const FftWs L = fft_ws(a);
     if (ws_bytes < L.total) { set_error("conv fwd (fft): workspace %zu < %zu", ws_bytes, L.total); return ZNS_ERR_WORKSPACE; }
@@ -699,7 +712,7 @@ static int fft_fwd_t(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float
     float* wf = (float*)(base + L.wf);
     int rc = run_spec_fwd(x, s_in, g.nb, a.cin, a.H, a.T, g, a.kw / 2, FN, 1.f, st);
     if (rc) return rc;
-    rc = run_fconv<C>(a, g, w, 0, s_in, s_out, wf, 0, st);
+    rc = run_fconv<C>(a, g, w, 0, s_in, s_out, wf, wpk, 0, st);
     if (rc) return rc;
     InvEpi E{};
     E.bias = bias;
@@ -715,8 +728,8 @@ static int fft_fwd_t(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float
 
 template <class C>
 static int fft_dgrad_t(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, const float* x, float inv_keep,
-                       const uint8_t* prev_argmax, int prev_pool, const float* dzspec, void* ws, size_t ws_bytes,
-                       hipStream_t st) {
+                       const uint8_t* prev_argmax, int prev_pool, const float* dzspec, const float* wpk, void* ws,
+                       size_t ws_bytes, hipStream_t st) {
     const FftGeom g = geom(a);
     const FftWs L = fft_ws(a);
     if (ws_bytes < L.total) { set_error("conv dgrad (fft): workspace %zu < %zu", ws_bytes, L.total); return ZNS_ERR_WORKSPACE; }
@@ -728,7 +741,7 @@ static int fft_dgrad_t(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, co
     if (dzspec) s_in = const_cast<float*>(dzspec);           // written by the preceding backward-weights call
     else rc = run_spec_fwd(dz, s_in, g.nb, a.cout, a.H, a.T, g, a.kw / 2, FN, 1.f, st);
     if (rc) return rc;
-    rc = run_fconv<C>(a, g, w, 1, s_in, s_out, wf, 1, st);
+    rc = run_fconv<C>(a, g, w, 1, s_in, s_out, wf, wpk, 1, st);
     if (rc) return rc;
     InvEpi E{};
     E.xmask = x;
@@ -794,44 +807,65 @@ static bool use_narrow(const ConvArgs& a) {
     return (long long)ceil_div(P, Narrow::WB) * Narrow::WB < (long long)ceil_div(P, Wide::WB) * Wide::WB;
 }
 
-int fft_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, uint8_t* argmax, float drop_p,
-            uint32_t seed, int layer, float* xspec, void* ws, size_t ws_bytes, hipStream_t st) {
+// One dispatcher for everything that depends on the (layer, tile variant) pair: F(tag<Cfg>) is called with the forward
+// (transposed == 0) or backward-data configuration the geometry runs on.
+template <class T> struct cfg_tag { typedef T type; };
+template <class Fn>
+static int with_cfg(const ConvArgs& a, int transposed, Fn&& f) {
     switch (fft_layer_of(a)) {
-        case 2: return fft_fwd_t<FF2>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
+        case 2: return transposed ? f(cfg_tag<FD2>{}) : f(cfg_tag<FF2>{});
         case 3:
-            if (use_narrow<FF3, FF3a>(a)) return fft_fwd_t<FF3a>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
-            return fft_fwd_t<FF3>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
+            if (transposed) return use_narrow<FD3, FD3a>(a) ? f(cfg_tag<FD3a>{}) : f(cfg_tag<FD3>{});
+            return use_narrow<FF3, FF3a>(a) ? f(cfg_tag<FF3a>{}) : f(cfg_tag<FF3>{});
         case 4:
-            if (use_narrow<FF4, FF4a>(a)) return fft_fwd_t<FF4a>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
-            return fft_fwd_t<FF4>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
+            if (transposed) return use_narrow<FD4, FD4a>(a) ? f(cfg_tag<FD4a>{}) : f(cfg_tag<FD4>{});
+            return use_narrow<FF4, FF4a>(a) ? f(cfg_tag<FF4a>{}) : f(cfg_tag<FF4>{});
         case 5:
-            if (use_narrow<FF5, FF5a>(a)) return fft_fwd_t<FF5a>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
-            return fft_fwd_t<FF5>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
+            if (transposed) return use_narrow<FD5, FD5a>(a) ? f(cfg_tag<FD5a>{}) : f(cfg_tag<FD5>{});
+            return use_narrow<FF5, FF5a>(a) ? f(cfg_tag<FF5a>{}) : f(cfg_tag<FF5>{});
         case 6:
-            if (use_narrow<FF6, FF6a>(a)) return fft_fwd_t<FF6a>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
-            return fft_fwd_t<FF6>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, ws, ws_bytes, st);
+            if (transposed) return use_narrow<FD6, FD6a>(a) ? f(cfg_tag<FD6a>{}) : f(cfg_tag<FD6>{});
+            return use_narrow<FF6, FF6a>(a) ? f(cfg_tag<FF6a>{}) : f(cfg_tag<FF6>{});
     }
     return ZNS_ERR_ARG;
 }
 
+int fft_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, uint8_t* argmax, float drop_p,
+            uint32_t seed, int layer, float* xspec, const float* wpk, void* ws, size_t ws_bytes, hipStream_t st) {
+    return with_cfg(a, 0, [&](auto t) {
+        return fft_fwd_t<typename decltype(t)::type>(a, x, w, bias, y, argmax, drop_p, seed, layer, xspec, wpk, ws, ws_bytes, st);
+    });
+}
+
 int fft_dgrad(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, const float* x, float inv_keep,
-              const uint8_t* prev_argmax, int prev_pool, const float* dzspec, void* ws, size_t ws_bytes, hipStream_t st) {
-    switch (fft_layer_of(a)) {
-        case 2: return fft_dgrad_t<FD2>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, dzspec, ws, ws_bytes, st);
-        case 3:
-            if (use_narrow<FD3, FD3a>(a)) return fft_dgrad_t<FD3a>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, dzspec, ws, ws_bytes, st);
-            return fft_dgrad_t<FD3>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, dzspec, ws, ws_bytes, st);
-        case 4:
-            if (use_narrow<FD4, FD4a>(a)) return fft_dgrad_t<FD4a>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, dzspec, ws, ws_bytes, st);
-            return fft_dgrad_t<FD4>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, dzspec, ws, ws_bytes, st);
-        case 5:
-            if (use_narrow<FD5, FD5a>(a)) return fft_dgrad_t<FD5a>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, dzspec, ws, ws_bytes, st);
-            return fft_dgrad_t<FD5>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, dzspec, ws, ws_bytes, st);
-        case 6:
-            if (use_narrow<FD6, FD6a>(a)) return fft_dgrad_t<FD6a>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, dzspec, ws, ws_bytes, st);
-            return fft_dgrad_t<FD6>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, dzspec, ws, ws_bytes, st);
-    }
-    return ZNS_ERR_ARG;
+              const uint8_t* prev_argmax, int prev_pool, const float* dzspec, const float* wpk, void* ws, size_t ws_bytes,
+              hipStream_t st) {
+    return with_cfg(a, 1, [&](auto t) {
+        return fft_dgrad_t<typename decltype(t)::type>(a, dz, w, dx, x, inv_keep, prev_argmax, prev_pool, dzspec, wpk, ws,
+                                                        ws_bytes, st);
+    });
+}
+
+// The frequency-weight layout depends on the tile variant (COB, CK, MT, WM), which the dispatcher picks from T: a packed
+// operand may be reused by any call whose layout id is the same.
+int fft_pack_layout(const ConvArgs& a, int transposed) {
+    const int l = fft_layer_of(a);
+    if (l < 0) return 0;
+    int narrow = 0;
+    with_cfg(a, transposed, [&](auto t) {
+        typedef typename decltype(t)::type C;
+        narrow = (std::is_same<C, FF3a>::value || std::is_same<C, FF4a>::value || std::is_same<C, FF5a>::value ||
+                  std::is_same<C, FF6a>::value || std::is_same<C, FD3a>::value || std::is_same<C, FD5a>::value) ? 1 : 0;
+        return ZNS_OK;
+    });
+    return 100 + 4 * l + 2 * narrow + (transposed ? 1 : 0);
+}
+size_t fft_pack_bytes(const ConvArgs& a, int transposed) {
+    (void)transposed;
+    return fft_layer_of(a) < 0 ? 0 : (size_t)a.nbr * FS * a.cout * a.cin * a.kh * sizeof(float);
+}
+int fft_pack(const ConvArgs& a, Ptr2 w, int transposed, float* dst, hipStream_t st) {
+    return with_cfg(a, transposed, [&](auto t) { return pack_fconv<typename decltype(t)::type>(a, w, transposed, dst, st); });
 }
 
 int fft_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, MPtr2 db, int accumulate,

@@ -119,17 +119,21 @@ static int pack_for(const ConvArgs& a, Ptr2 w, float* dst, int transposed, hipSt
 }
 
 template <class C>
-static int launch_core(const ConvArgs& a, CoreArgs A, Ptr2 w, int transposed, void* ws, size_t ws_bytes,
-                       hipStream_t st) {
-    if (ws_bytes < packed_bytes(a)) {
-        set_error("conv: workspace %zu < %zu", ws_bytes, packed_bytes(a));
-        return ZNS_ERR_WORKSPACE;
+static int launch_core(const ConvArgs& a, CoreArgs A, Ptr2 w, int transposed, const float* wpk, void* ws,
+                       size_t ws_bytes, hipStream_t st) {
+    int rc = ZNS_OK;
+    if (wpk == nullptr) {
+        if (ws_bytes < packed_bytes(a)) {
+            set_error("conv: workspace %zu < %zu", ws_bytes, packed_bytes(a));
+            return ZNS_ERR_WORKSPACE;
+        }
+        rc = pack_for<C>(a, w, (float*)ws, transposed, st);
+        if (rc) return rc;
+        wpk = (const float*)ws;
     }
-    int rc = pack_for<C>(a, w, (float*)ws, transposed, st);
-    if (rc) return rc;
     rc = set_lds<C>(conv_core<C>);
     if (rc) return rc;
-    A.wpk = (const float*)ws;
+    A.wpk = wpk;
     A.B = a.B;
     A.T = a.T;
     A.N = a.nbr * a.B;
@@ -145,7 +149,7 @@ static int launch_core(const ConvArgs& a, CoreArgs A, Ptr2 w, int transposed, vo
 }
 
 int mfma_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, uint8_t* argmax, float drop_p,
-             uint32_t seed, int layer, void* ws, size_t ws_bytes, hipStream_t st) {
+             uint32_t seed, int layer, const float* wpk, void* ws, size_t ws_bytes, hipStream_t st) {
     CoreArgs A{};
     A.x = x;
     A.bias = bias;
@@ -156,19 +160,19 @@ int mfma_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, uin
     A.seed = seed;
     A.layer = layer;
     switch (layer_of(a)) {
-        case 2: return launch_core<F2>(a, A, w, 0, ws, ws_bytes, st);
-        case 3: return launch_core<F3>(a, A, w, 0, ws, ws_bytes, st);
-        case 4: return launch_core<F4>(a, A, w, 0, ws, ws_bytes, st);
-        case 5: return launch_core<F5>(a, A, w, 0, ws, ws_bytes, st);
-        case 6: return launch_core<F6>(a, A, w, 0, ws, ws_bytes, st);
-        case 7: return launch_core<F7>(a, A, w, 0, ws, ws_bytes, st);
-        case 8: return launch_core<F8>(a, A, w, 0, ws, ws_bytes, st);
+        case 2: return launch_core<F2>(a, A, w, 0, wpk, ws, ws_bytes, st);
+        case 3: return launch_core<F3>(a, A, w, 0, wpk, ws, ws_bytes, st);
+        case 4: return launch_core<F4>(a, A, w, 0, wpk, ws, ws_bytes, st);
+        case 5: return launch_core<F5>(a, A, w, 0, wpk, ws, ws_bytes, st);
+        case 6: return launch_core<F6>(a, A, w, 0, wpk, ws, ws_bytes, st);
+        case 7: return launch_core<F7>(a, A, w, 0, wpk, ws, ws_bytes, st);
+        case 8: return launch_core<F8>(a, A, w, 0, wpk, ws, ws_bytes, st);
     }
     return ZNS_ERR_ARG;
 }
 
 int mfma_dgrad(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, const float* x, float inv_keep,
-               const uint8_t* prev_argmax, int prev_pool, void* ws, size_t ws_bytes, hipStream_t st) {
+               const uint8_t* prev_argmax, int prev_pool, const float* wpk, void* ws, size_t ws_bytes, hipStream_t st) {
     CoreArgs A{};
     A.x = dz;
     A.dx = dx;
@@ -177,13 +181,38 @@ int mfma_dgrad(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, const floa
     A.prev_argmax = prev_argmax;
     A.prev_pool = prev_pool;
     switch (layer_of(a)) {
-        case 2: return launch_core<D2>(a, A, w, 1, ws, ws_bytes, st);
-        case 3: return launch_core<D3>(a, A, w, 1, ws, ws_bytes, st);
-        case 4: return launch_core<D4>(a, A, w, 1, ws, ws_bytes, st);
-        case 5: return launch_core<D5>(a, A, w, 1, ws, ws_bytes, st);
-        case 6: return launch_core<D6>(a, A, w, 1, ws, ws_bytes, st);
-        case 7: return launch_core<D7>(a, A, w, 1, ws, ws_bytes, st);
-        case 8: return launch_core<D8>(a, A, w, 1, ws, ws_bytes, st);
+        case 2: return launch_core<D2>(a, A, w, 1, wpk, ws, ws_bytes, st);
+        case 3: return launch_core<D3>(a, A, w, 1, wpk, ws, ws_bytes, st);
+        case 4: return launch_core<D4>(a, A, w, 1, wpk, ws, ws_bytes, st);
+        case 5: return launch_core<D5>(a, A, w, 1, wpk, ws, ws_bytes, st);
+        case 6: return launch_core<D6>(a, A, w, 1, wpk, ws, ws_bytes, st);
+        case 7: return launch_core<D7>(a, A, w, 1, wpk, ws, ws_bytes, st);
+        case 8: return launch_core<D8>(a, A, w, 1, wpk, ws, ws_bytes, st);
+    }
+    return ZNS_ERR_ARG;
+}
+
+int mfma_pack_layout(const ConvArgs& a, int transposed) {
+    const int l = layer_of(a);
+    return l > 0 ? 200 + 2 * l + (transposed ? 1 : 0) : 0;
+}
+size_t mfma_pack_bytes(const ConvArgs& a, int transposed) { (void)transposed; return layer_of(a) > 0 ? packed_bytes(a) : 0; }
+int mfma_pack(const ConvArgs& a, Ptr2 w, int transposed, float* dst, hipStream_t st) {
+    switch (layer_of(a) * 2 + (transposed ? 1 : 0)) {
+        case 4: return pack_for<F2>(a, w, dst, 0, st);
+        case 5: return pack_for<D2>(a, w, dst, 1, st);
+        case 6: return pack_for<F3>(a, w, dst, 0, st);
+        case 7: return pack_for<D3>(a, w, dst, 1, st);
+        case 8: return pack_for<F4>(a, w, dst, 0, st);
+        case 9: return pack_for<D4>(a, w, dst, 1, st);
+        case 10: return pack_for<F5>(a, w, dst, 0, st);
+        case 11: return pack_for<D5>(a, w, dst, 1, st);
+        case 12: return pack_for<F6>(a, w, dst, 0, st);
+        case 13: return pack_for<D6>(a, w, dst, 1, st);
+        case 14: return pack_for<F7>(a, w, dst, 0, st);
+        case 15: return pack_for<D7>(a, w, dst, 1, st);
+        case 16: return pack_for<F8>(a, w, dst, 0, st);
+        case 17: return pack_for<D8>(a, w, dst, 1, st);
     }
     return ZNS_ERR_ARG;
 }

@@ -30,10 +30,14 @@ int channel_sum(int nbr, int B, int C, long long HT, const float* dz, MPtr2 db, 
 // zns_conv_mfma.hip -- return ZNS_ERR_ARG (without setting an error) when the shape has no instance
 bool mfma_supported(const ConvArgs& a);
 size_t mfma_workspace_bytes(const ConvArgs& a);
+// wpk (nullable): operand already packed by mfma_pack for the same geometry -- the call then skips its own packing
 int mfma_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, uint8_t* argmax, float drop_p,
-             uint32_t seed, int layer, void* ws, size_t ws_bytes, hipStream_t st);
+             uint32_t seed, int layer, const float* wpk, void* ws, size_t ws_bytes, hipStream_t st);
 int mfma_dgrad(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, const float* x, float inv_keep,
-               const uint8_t* prev_argmax, int prev_pool, void* ws, size_t ws_bytes, hipStream_t st);
+               const uint8_t* prev_argmax, int prev_pool, const float* wpk, void* ws, size_t ws_bytes, hipStream_t st);
+int mfma_pack_layout(const ConvArgs& a, int transposed);     // > 0: id of the operand layout this geometry's kernel reads
+size_t mfma_pack_bytes(const ConvArgs& a, int transposed);
+int mfma_pack(const ConvArgs& a, Ptr2 w, int transposed, float* dst, hipStream_t st);
 int mfma_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, int accumulate, void* ws,
                size_t ws_bytes, hipStream_t st);
 
@@ -44,9 +48,13 @@ size_t fft_workspace_bytes(const ConvArgs& a);
 size_t fft_spectrum_bytes(const ConvArgs& a);   // input spectrum shared by forward and backward-weights
 size_t fft_dz_spectrum_bytes(const ConvArgs& a);   // dZ spectrum shared by backward-weights and backward-data
 int fft_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, uint8_t* argmax, float drop_p,
-            uint32_t seed, int layer, float* xspec, void* ws, size_t ws_bytes, hipStream_t st);
+            uint32_t seed, int layer, float* xspec, const float* wpk, void* ws, size_t ws_bytes, hipStream_t st);
 int fft_dgrad(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, const float* x, float inv_keep,
-              const uint8_t* prev_argmax, int prev_pool, const float* dzspec, void* ws, size_t ws_bytes, hipStream_t st);
+              const uint8_t* prev_argmax, int prev_pool, const float* dzspec, const float* wpk, void* ws,
+              size_t ws_bytes, hipStream_t st);
+int fft_pack_layout(const ConvArgs& a, int transposed);      // > 0: id of the frequency-weight layout (wide / narrow tile variant)
+size_t fft_pack_bytes(const ConvArgs& a, int transposed);
+int fft_pack(const ConvArgs& a, Ptr2 w, int transposed, float* dst, hipStream_t st);
 int fft_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, MPtr2 db, int accumulate,
               const float* xspec, float* dzspec_out, void* ws, size_t ws_bytes, hipStream_t st);   // also writes the bias gradient
 

@@ -47,4 +47,5 @@ class Adam(torch.optim.Optimizer):
                                              st["exp_avg_sq"].data_ptr(), p.numel(), group["lr"], b1, b2,
                                              group["eps"], st["step"], 1.0, _ops.stream_ptr(p.device))
                 _lib.check(rc, "zns_adam_step_f32")
+                _ops.bump_version(p)       # written through the raw pointer: invalidate cached packed operands
         return loss

@@ -334,6 +334,7 @@ class PretextTrainer:
                                               self.betas[1], self.eps, self.step_count, 1.0 / self.world,
                                               _ops.stream_ptr(x.device))
             _lib.check(rc, "zns_adam_step_f32")
+            _ops.bump_version(self.flat_p)     # every parameter is a view of it: cached packed operands are stale now
         return out3
 
     @torch.no_grad()
