@@ -22,6 +22,19 @@ __device__ __forceinline__ void glds16(const float* src, float* lds_dst) {
     __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)lds_dst, 16, 0, 0);
 }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// LDS-DMA through a buffer descriptor: wave-uniform base in SGPRs, ONE 32-bit per-lane byte offset, and hardware range
+// checking (a lane whose offset is >= num_records moves zeros): no 64-bit per-lane pointer arithmetic, no select
+// against a zero page.  BUF_OOB marks a lane that must read zero.
+constexpr unsigned BUF_OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const float* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void blds4(__amdgpu_buffer_rsrc_t rs, unsigned voff, float* lds_dst) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)lds_dst, 4, (int)voff, 0, 0, 0);
+}
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rs, unsigned voff, float* lds_dst) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)lds_dst, 16, (int)voff, 0, 0, 0);
+}
 
 // MFMA 32x32 accumulator: lane&31 = column, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 __device__ __forceinline__ int acc_row(int reg, int lane_h) { return (reg & 3) + 8 * (reg >> 2) + 4 * lane_h; }
@@ -485,6 +498,7 @@ struct WgCfg {
     static constexpr int ZBUF = COB * CW;                    // dZ tile [COB][CW], 16-byte chunks XOR-swizzled by the key above
     static constexpr int XBUF = ((CIB * PS + 63) / 64) * 64;
     static constexpr int NXI = (XBUF / 64 + NW - 1) / NW;    // X-patch DMA instructions per wave
+    static constexpr int NZI = (COB / RPI + NW - 1) / NW;    // dZ-tile DMA instructions per wave (16-byte pieces)
     static constexpr int LDS_BYTES = 2 * (ZBUF + XBUF) * 4;
     static_assert(R == 1, "one image row per K-tile");
     static_assert(CW == 32 || CW == 64, "K-tile width");
@@ -505,11 +519,15 @@ struct WgArgs {
 // Stage one K-tile (image row h0, columns w0..w0+63 of sample n):
 //   dZ  [COB][64]            16-byte chunk c of channel co is stored at chunk position c ^ (co & 15)
 //   X   [32][PRW][PCW] (+pad) rows h0+r0-PH .., columns w0-PW .., zero outside the image
-// xrel / xrc: per-lane source offsets of this wave's X-patch DMA instructions, computed once per kernel.
+// Both go through buffer descriptors rebuilt per tile from scalars (base = tile origin): the per-lane byte offsets
+// xvoff / zvoff are tile independent and computed once per kernel, so an interior tile costs one buffer_load..lds plus an
+// M0 update per 256-byte / 1-KiB piece and NO vector ALU work (the previous per-lane 64-bit pointer + zero-page select
+// version spent ~900 scalar/vector instructions per stage, a fifth of the stage, with the matrix pipes idle).
+// xrc: (row << 16 | col) of the lane's element inside the patch, for the tiles that touch the image border.
 template <class C>
 __device__ __forceinline__ void wg_load_tile(const WgArgs& A, int br, int cob, int cit, int r0, int tile, float* zb,
-                                             float* xb, int wid, int lane, const int (&xrel)[C::NXI],
-                                             const int (&xrc)[C::NXI], int pcw, int nxq) {
+                                             float* xb, int wid, int lane, const unsigned (&xvoff)[C::NXI],
+                                             const int (&xrc)[C::NXI], const unsigned (&zvoff)[C::NZI], int pcw, int nxq) {
     const int T = A.T;
     const int cbk = tile % A.ncb;
     const int h0 = (tile / A.ncb) % C::H;
@@ -521,10 +539,11 @@ __device__ __forceinline__ void wg_load_tile(const WgArgs& A, int br, int cob, i
     const bool fastz = ((T & 3) == 0) && (w0 + C::CW <= T) && ((reinterpret_cast<uintptr_t>(A.dz) & 15) == 0);
     if (fastz) {
         // LPR lanes x 16 B = one row segment; one DMA instruction stages RPI channels (1 KiB, LDS-linear)
-        for (int q = wid; q < C::COB / C::RPI; q += C::NW) {
-            const int co = C::RPI * q + lane / C::LPR;
-            const int c = (lane % C::LPR) ^ ((co / C::ZKD) & (C::LPR - 1));
-            glds16(zrow + (size_t)co * zplane + c * 4, zb + q * 256);
+        const __amdgpu_buffer_rsrc_t rz = buf_rsrc(zrow, (unsigned)(((C::COB - 1) * zplane + C::CW) * sizeof(float)));
+#pragma unroll
+        for (int i = 0; i < C::NZI; ++i) {
+            const int q = wid + i * C::NW;
+            if (q < C::COB / C::RPI) blds16(rz, zvoff[i], zb + q * 256);
         }
     } else {
         for (int q = wid; q < C::COB * C::CW / 64; q += C::NW) {
@@ -537,17 +556,23 @@ __device__ __forceinline__ void wg_load_tile(const WgArgs& A, int br, int cob, i
     const int hbase = h0 + r0 - C::PH, wbase = w0 - (C::DILMAX ? (C::KW / 2) * A.dil : C::PW);
     const bool interior = hbase >= 0 && hbase + C::PRW <= C::H && wbase >= 0 && wbase + pcw <= T;
     const float* xbase = A.x + ((size_t)n * C::CIN + (size_t)cit * C::CIB) * C::H * T + (ptrdiff_t)hbase * T + wbase;
+    const __amdgpu_buffer_rsrc_t rx =
+        buf_rsrc(xbase, (unsigned)((((size_t)(C::CIB - 1) * C::H + C::PRW - 1) * T + pcw) * sizeof(float)));
+    if (interior) {
 #pragma unroll
-    for (int i = 0; i < C::NXI; ++i) {
-        const int q = wid + i * C::NW;
-        if (q < nxq) {
-            bool ok = xrel[i] >= 0;
-            if (!interior) {
+        for (int i = 0; i < C::NXI; ++i) {
+            const int q = wid + i * C::NW;
+            if (q < nxq) blds4(rx, xvoff[i], xb + q * 64);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < C::NXI; ++i) {
+            const int q = wid + i * C::NW;
+            if (q < nxq) {
                 const int hh = hbase + (xrc[i] >> 16), ww = wbase + (xrc[i] & 0xffff);
-                ok = ok && (unsigned)hh < (unsigned)C::H && (unsigned)ww < (unsigned)T;
+                const bool ok = (unsigned)hh < (unsigned)C::H && (unsigned)ww < (unsigned)T;
+                blds4(rx, ok ? xvoff[i] : BUF_OOB, xb + q * 64);
             }
-            const float* src = ok ? xbase + xrel[i] : g_zero_page;
-            glds4(src, xb + q * 64);
         }
     }
 }
@@ -589,8 +614,9 @@ __global__ void __launch_bounds__(C::NT) wgrad_core(WgArgs A) {
     const int pcw = C::DILMAX ? C::CW + (C::KW - 1) * A.dil : C::PCW;
     const int ps = C::DILMAX ? ((C::PRW * pcw) | 1) : C::PS;
     const int nxq = C::DILMAX ? (C::CIB * ps + 63) / 64 : C::XBUF / 64;
-    // X-patch DMA source offsets of this wave (tile independent)
-    int xrel[C::NXI], xrc[C::NXI];
+    // per-lane source byte offsets of this wave's DMA instructions, relative to the tile origin (tile independent)
+    unsigned xvoff[C::NXI], zvoff[C::NZI];
+    int xrc[C::NXI];
 #pragma unroll
     for (int i = 0; i < C::NXI; ++i) {
         const int L = (wid + i * C::NW) * 64 + lane;
@@ -599,8 +625,15 @@ __global__ void __launch_bounds__(C::NT) wgrad_core(WgArgs A) {
         const int row = rem / pcw;
         const int col = rem - row * pcw;
         const bool ok = ci < C::CIB && row < C::PRW;
-        xrel[i] = ok ? (ci * C::H + row) * A.T + col : -1;
+        xvoff[i] = ok ? (unsigned)(((ci * C::H + row) * A.T + col) * 4) : BUF_OOB;
         xrc[i] = (row << 16) | col;
+    }
+#pragma unroll
+    for (int i = 0; i < C::NZI; ++i) {
+        const int q = wid + i * C::NW;
+        const int co = C::RPI * q + lane / C::LPR;
+        const int c = (lane % C::LPR) ^ ((co / C::ZKD) & (C::LPR - 1));
+        zvoff[i] = (unsigned)((co * C::H * A.T + c * 4) * 4);
     }
 
     // per-lane LDS read bases.  A (dZ): channel = lane_j, 4 consecutive pixels per ds_read_b128; the k index of MFMA s
@@ -616,13 +649,14 @@ __global__ void __launch_bounds__(C::NT) wgrad_core(WgArgs A) {
         xoff[s] = (wci * 32 + lane_j) * ps + (rr - r0) * pcw + (C::DILMAX ? ss * A.dil : ss) + 4 * lane_h;
     }
 
-    if (t_begin < t_end) wg_load_tile<C>(A, br, cob, cit, r0, t_begin, zbuf(0), xbuf(0), wid, lane, xrel, xrc, pcw, nxq);
+    if (t_begin < t_end)
+        wg_load_tile<C>(A, br, cob, cit, r0, t_begin, zbuf(0), xbuf(0), wid, lane, xvoff, xrc, zvoff, pcw, nxq);
     int cur = 0;
     for (int tile = t_begin; tile < t_end; ++tile, cur ^= 1) {
         wait_vm0();
         __syncthreads();
         if (tile + 1 < t_end)
-            wg_load_tile<C>(A, br, cob, cit, r0, tile + 1, zbuf(cur ^ 1), xbuf(cur ^ 1), wid, lane, xrel, xrc, pcw, nxq);
+            wg_load_tile<C>(A, br, cob, cit, r0, tile + 1, zbuf(cur ^ 1), xbuf(cur ^ 1), wid, lane, xvoff, xrc, zvoff, pcw, nxq);
         const float* __restrict__ zp = zbuf(cur) + zrowbase;
         const float* __restrict__ xp = xbuf(cur);
 #pragma unroll

@@ -20,6 +20,7 @@
 // i.e. 3*32 real MACs per window position instead of V*kw: 6.8x (cv2) .. 9.4x (cv6) fewer than the direct form.
 // Spectra live in the workspace as S[sample][slot = 3 f + t][C][P], P = H*NB, planes t = (re, im, re +/- im);
 // frequency slot 0 carries the two real bins (DC in t = 0, Nyquist in t = 1, t = 2 unused).
+#include <cstdlib>
 #include <type_traits>
 
 #include "zns_conv_core.h"
