@@ -270,6 +270,15 @@ class PretextTrainer:
         sc = torch.tensor([self.step_count], dtype=torch.int64, device=self.flat_p.device)
         broadcast_tensors((self.flat_p, self.flat_m, self.flat_v, sc), src=src, group=self.pg)
         self.step_count = int(sc.item())
+        self._params_written()
+
+    def _params_written(self) -> None:
+        """The flat buffer was written through its raw pointer (fused Adam, broadcast): bump every parameter's autograd
+        version -- a Parameter whose `.data` is a view of the flat buffer keeps its OWN version counter, so bumping the
+        buffer alone would leave the cached packed operands (_ops.packed_weights) looking current."""
+        _ops.bump_version(self.flat_p)
+        for p, _ in self._views:
+            _ops.bump_version(p)
 
     def _check_flat(self) -> None:
         for p, ptr in self._views:
@@ -334,7 +343,7 @@ class PretextTrainer:
                                               self.betas[1], self.eps, self.step_count, 1.0 / self.world,
                                               _ops.stream_ptr(x.device))
             _lib.check(rc, "zns_adam_step_f32")
-            _ops.bump_version(self.flat_p)     # every parameter is a view of it: cached packed operands are stale now
+            self._params_written()
         return out3
 
     @torch.no_grad()
