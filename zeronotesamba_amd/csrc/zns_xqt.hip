@@ -21,6 +21,8 @@
 
 namespace zns {
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
 namespace {
 
 constexpr int XQ_SR = 16000, XQ_HOP = 256, XQ_BINS = 96, XQ_BPO = 12, XQ_OCT = 8;
@@ -38,7 +40,8 @@ struct Bank {
     int n_fft[XQ_OCT];
     int hop[XQ_OCT];
     int off[XQ_OCT];        // float2 offset of octave i inside `fir`
-    float2* fir = nullptr;  // device: [octave][n_fft][12] complex (tap-major: one frame step reads 12 neighbours)
+    float* fira = nullptr;  // device: MFMA A operand of the filter bank, [octave][n_fft / 2 k-steps][64 lanes]
+    int offa[XQ_OCT];       // float offset of octave i inside `fira`
     DecTaps* taps = nullptr;   // device: float64 decimation taps
     bool ready = false;
 };
@@ -158,17 +161,24 @@ int ensure_bank(int mode, Bank** out) {
             b.off[i] = (int)total;
             total += fir[i].size();
         }
-        std::vector<float2> h(total);
+        // A operand of v_mfma_f32_32x32x2_f32 for the GEMM  D[row][frame] = sum_n A[row][n] * B[n][frame]:
+        // row 2k = Re g_k, row 2k+1 = Im g_k (k < 12; rows 24..31 are zero), k-step s holds taps n = 2s, 2s+1;
+        // lane l supplies A[l & 31][2s + (l >> 5)]
+        size_t tota = 0;
+        for (int i = 0; i < XQ_OCT; ++i) { b.offa[i] = (int)tota; tota += (size_t)(b.n_fft[i] / 2) * 64; }
+        std::vector<float> ha(tota, 0.f);
         for (int i = 0; i < XQ_OCT; ++i)
-            for (int k = 0; k < XQ_BPO; ++k)
-                for (int j = 0; j < b.n_fft[i]; ++j) {
-                    const std::complex<double> c = fir[i][(size_t)k * b.n_fft[i] + j];
-                    h[b.off[i] + (size_t)j * XQ_BPO + k] = make_float2((float)c.real(), (float)c.imag());
+            for (int sidx = 0; sidx < b.n_fft[i] / 2; ++sidx)
+                for (int l = 0; l < 64; ++l) {
+                    const int row = l & 31, n = 2 * sidx + (l >> 5);
+                    if (row >= 2 * XQ_BPO) continue;
+                    const std::complex<double> c = fir[i][(size_t)(row >> 1) * b.n_fft[i] + n];
+                    ha[b.offa[i] + (size_t)sidx * 64 + l] = (float)((row & 1) ? c.imag() : c.real());
                 }
         double taps[NL + NR];
         build_taps(taps, taps + NL);
-        ZNS_HIP(hipMalloc(&b.fir, total * sizeof(float2)));
-        ZNS_HIP(hipMemcpy(b.fir, h.data(), total * sizeof(float2), hipMemcpyHostToDevice));
+        ZNS_HIP(hipMalloc(&b.fira, tota * sizeof(float)));
+        ZNS_HIP(hipMemcpy(b.fira, ha.data(), tota * sizeof(float), hipMemcpyHostToDevice));
         ZNS_HIP(hipMalloc(&b.taps, sizeof(DecTaps)));
         ZNS_HIP(hipMemcpy(b.taps, taps, sizeof(taps), hipMemcpyHostToDevice));
         b.ready = true;
@@ -313,97 +323,224 @@ __global__ void __launch_bounds__(256) decimate_chain_kernel(DecChain P, const D
 struct XqtLevels {
     const float* y[XQ_OCT];
     long long stride[XQ_OCT];
+    int vec[XQ_OCT];          // rows of this level are 16-byte aligned (base and stride)
     int len[XQ_OCT];
     int n_fft[XQ_OCT];
     int hop[XQ_OCT];
     int off[XQ_OCT];
 };
 
-constexpr int XQ_FPB = 64;   // frames per block
-constexpr int XQ_GRP = 4;    // filter groups per block (3 filters each): 256 threads
+// ---------------------------------------------------------------------------------------------------------
+// Filter bank: V[k][t] = sum_n g_k[n] * ypad_i[t * hop_i + n] for the 12 filters of every octave, then log(|V| + 1e-9).
+//
+// Per octave this is a small dense GEMM  D[24 real rows][frames] = A[24][n_fft] * B[n_fft][frames]  (B is the strided
+// view B[n][t] = ypad[t hop + n] of the octave's signal): it runs on the fp32 matrix cores as tiles of 32 frames, one
+// v_mfma_f32_32x32x2_f32 per two taps.  fp32 MFMA has the fp32 FMA peak, so nothing is gained in rate (24 of the 32 rows
+// are used) -- what it buys is operand delivery: the whole A operand (the octave's filter bank) sits in n_fft / 2
+// registers per lane for as many tiles as the wave processes, and B costs ONE conflict-free ds_read_b32 per MFMA, where
+// the previous per-thread FMA kernel spent its time streaming taps through the scalar cache and frames through LDS
+// (16 % of the FMA peak).  The accumulation order per output is n = 0, 1, 2, ... exactly as a scalar fmaf chain (an fp32
+// MFMA is bit for bit an fmaf chain), so results are identical to the kernel this replaces.
+//
+// Work split: a block owns FB_TPB consecutive 32-frame tiles of one clip; its four waves share the (octave, tile) items
+// along a host-built schedule (longest-processing-time over the octaves' MFMA counts, 64..8 per tile, then tile-level
+// rebalancing): a wave loads an octave's A operand once and walks that octave's tiles.  Every wave stages its tile's
+// signal segment into its OWN LDS region (no workgroup barrier anywhere): element u of the segment lives at
+// u + u / hopL (hopL = min(hop, n_fft): one pad word per frame step), so lane j's operand (frame j, tap c) sits at
+// j (hopL + 1) + c + c / hopL -- an odd lane stride for every octave: conflict free.
+constexpr int FB_TPB = 4;          // tiles of 32 frames per block (fewer for small batches: see zns_xqt_stages_f32)
+constexpr int FB_MAXRUN = 32;
 
-struct TapChunk {
-    float2 c[4][3];   // 4 consecutive taps x 3 filters, wave-uniform
+struct FbRun {
+    unsigned char wave, oct, tile0, ntile;
+};
+struct FbArgs {
+    XqtLevels L;
+    const float* fira;
+    int offa[XQ_OCT];
+    int n_frames, tiles, tpb, blocks_per_clip, nruns, wave_floats;
+    FbRun run[FB_MAXRUN];
+    float* out;
 };
 
-__device__ __forceinline__ void load_taps(TapChunk& d, const float2* __restrict__ g) {
+template <int NFFT>
+__device__ __forceinline__ void fb_run(const FbArgs& P, const FbRun r, int clip, int tile_base, float* __restrict__ lw,
+                                       int lane) {
+    const int oct = r.oct;
+    const int hop = P.L.hop[oct], len = P.L.len[oct];
+    const int hopL = hop < NFFT ? hop : NFFT;
+    const int lg = 31 - __builtin_clz(hopL);
+    const float* __restrict__ y = P.L.y[oct] + (long long)clip * P.L.stride[oct];
+    float a[NFFT / 2];
+    const float* __restrict__ ga = P.fira + P.offa[oct] + lane;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int s = 0; s < NFFT / 2; ++s) a[s] = ga[s * 64];
+    const int j = lane & 31, kk = lane >> 5;
+    // Tile = frames t0 .. t0+31 with librosa's center=True reflect padding of n_fft / 2 at both ends of the signal.
+    // Element e of a tile: windows layout (hop >= n_fft) e = f * n_fft + c, else the contiguous segment e = u; at most
+    // 32 * n_fft elements = NV float4 per lane.  An interior tile travels global -> registers -> LDS, 16 bytes per lane,
+    // and its registers are loaded while the PREVIOUS tile is being multiplied (one memory latency per run of tiles is
+    // exposed, not one per tile); the two tiles at the ends of the signal are staged element by element.
+    constexpr int NV = NFFT / 8;
+    const bool win = hop >= NFFT;
+    const int nel = win ? 32 * NFFT : 31 * hop + NFFT;
+    const bool vec_ok = (hop & 3) == 0 && P.L.vec[oct];
+    auto dst = [&](int e) { return win ? (e / NFFT) * (NFFT + 1) + (e & (NFFT - 1)) : e + (e >> lg); };
+    float4 v[NV];
+    auto interior = [&](int t0) {      // the tile touches neither end of the signal and can move 16 bytes per lane
+        return vec_ok && t0 * hop - NFFT / 2 >= 0 && (t0 + 31) * hop + NFFT / 2 <= len;
+    };
+    // lane's float4 number u is element e = 256 u + 4 lane: both its source and its LDS position are (lane part) + u * (a
+    // wave-uniform stride), because n_fft and hopL divide 256 -- one address per lane, immediates / scalars for the rest
+    const int e0 = 4 * lane;
+    const int sstride = win ? (256 / NFFT) * hop : 256;                        // source floats between consecutive u
+    const int dstride = win ? (256 / NFFT) * (NFFT + 1) : 256 + (256 >> lg);   // LDS floats between consecutive u
+    const int soff0 = win ? (e0 / NFFT) * hop + (e0 & (NFFT - 1)) : e0;
+    float* __restrict__ lp = lw + dst(e0);
+    auto load_tile = [&](int t0) {     // interior tiles only: global -> registers
+        const float* __restrict__ sp = y + (t0 * hop - NFFT / 2 + soff0);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) d.c[j][k] = g[j * XQ_BPO + k];
-}
-
-__device__ __forceinline__ void apply_taps(const TapChunk& tc, const float* x, float* re, float* im) {
+        for (int u = 0; u < NV; ++u)
+            if (256 * u + e0 < nel) v[u] = *reinterpret_cast<const float4*>(sp + u * sstride);
+    };
+    auto store_tile = [&]() {          // registers -> LDS (hopL is a multiple of 4 here: the 4 floats stay adjacent)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+        for (int u = 0; u < NV; ++u)
+            if (256 * u + e0 < nel) {
+                float* d = lp + u * dstride;
+                d[0] = v[u].x;
+                d[1] = v[u].y;
+                d[2] = v[u].z;
+                d[3] = v[u].w;
+            }
+    };
+    auto stage_edge = [&](int t0) {    // tiles at the ends of the signal (and unaligned rows): element-wise, reflected
+        const int m_lo = t0 * hop - NFFT / 2;
+        for (int base = 0; base < nel; base += 64 * 8) {
+            float w[8];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            re[k] = fmaf(tc.c[j][k].x, x[j], re[k]);
-            im[k] = fmaf(tc.c[j][k].y, x[j], im[k]);
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + u * 64 + lane;
+                int m = win ? (t0 + e / NFFT) * hop + (e & (NFFT - 1)) - NFFT / 2 : m_lo + e;
+                m = m < 0 ? -m : m;
+                m = m >= len ? 2 * (len - 1) - m : m;
+                m = m < 0 ? 0 : (m >= len ? len - 1 : m);                               // frames past the last one are never written out
+                w[u] = y[m];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = base + u * 64 + lane;
+                if (e < nel) lw[dst(e)] = w[u];
+            }
         }
-}
-
-// block: 64 consecutive frames of one (octave, clip); 256 threads = 64 frames x 4 groups of 3 filters.
-// The frames' windows are staged into LDS with coalesced loads, 8 in flight per thread (row stride n_fft + 1:
-// conflict-free per-frame reads).  The filter taps are wave-uniform: they stream through the scalar cache from the
-// tap-major [n][12] device layout, one 4-tap chunk ahead of the FMAs (the x values are fetched from LDS one chunk
-// ahead too, because LDS and scalar loads share a wait counter).
-__global__ void __launch_bounds__(256) xqt_filter_kernel(XqtLevels L, const float2* __restrict__ fir, int n_frames,
-                                                         float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float rows[];
-    const int oct = blockIdx.y, clip = blockIdx.z;
-    const int n_fft = L.n_fft[oct], hop = L.hop[oct], len = L.len[oct];
-    const int lg = 31 - __builtin_clz(n_fft);
-    const int f0 = blockIdx.x * XQ_FPB;
-    const float* y = L.y[oct] + (long long)clip * L.stride[oct];
-    const int rs = n_fft + 1;
-    // XQ_FPB * n_fft is a multiple of 256 * 4 (n_fft >= 16)
-    for (int i0 = threadIdx.x; i0 < XQ_FPB * n_fft; i0 += 256 * 4) {
-        float v[4];
+    };
+    const int first = tile_base + r.tile0;
+    if (first >= P.tiles) return;
+    bool pre = interior(first * 32);
+    if (pre) load_tile(first * 32);
+    for (int ti = 0; ti < r.ntile; ++ti) {
+        const int tile = first + ti;
+        if (tile >= P.tiles) break;
+        const int t0 = tile * 32;
+        if (pre) store_tile(); else stage_edge(t0);     // the previous tile's operand reads have all been consumed
+        pre = ti + 1 < r.ntile && tile + 1 < P.tiles && interior(t0 + 32);
+        if (pre) load_tile(t0 + 32);                    // in flight while this tile is multiplied
+        // same-wave LDS traffic is ordered: no barrier between the writes above and the reads below
+        f32x16 acc;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * 256;
-            const int f = i >> lg, n = i & (n_fft - 1);
-            int idx = (f0 + f) * hop - n_fft / 2 + n;
-            if (idx < 0) idx = -idx;                       // np.pad(mode="reflect")
-            if (idx >= len) idx = 2 * (len - 1) - idx;
-            idx = idx < 0 ? 0 : idx;                       // frames past the end are never written out
-            v[u] = (f0 + f < n_frames) ? y[idx] : 0.f;
+        for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+        const float* __restrict__ bp = lw + j * (hopL + 1) + kk;
+        // operands are read 8 k-steps at a time (a scheduling fence keeps the compiler from hoisting all n_fft / 2 reads
+        // into registers at once: with the A operand and the prefetched tile resident that would spill)
+#pragma unroll
+        for (int s0 = 0; s0 < NFFT / 2; s0 += 8) {
+            float bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bv[u] = bp[2 * (s0 + u) + ((2 * (s0 + u)) >> lg)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s0 + u], bv[u], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        // ---- rows 2k / 2k+1 of one filter are neighbouring registers of one lane: |V|, log, coalesced along time
+        const int t = t0 + j;
+        if (t < P.n_frames) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * 256;
-            rows[(i >> lg) * rs + (i & (n_fft - 1))] = v[u];
+            for (int q = 0; q < 6; ++q) {
+                const int k = (q & 1) + 4 * (q >> 1) + 2 * kk;                       // row = (reg & 3) + 8 (reg >> 2) + 4 kk, reg = 2q
+                const float re = acc[2 * q], im = acc[2 * q + 1];
+                const int kbin = XQ_BINS - XQ_BPO * (oct + 1) + k;
+                P.out[((size_t)clip * XQ_BINS + kbin) * P.n_frames + t] = logf(sqrtf(re * re + im * im) + 1e-9f);
+            }
         }
     }
-    __syncthreads();
-    const int f = threadIdx.x & 63;
-    const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const float2* gf = fir + L.off[oct] + g * 3;
-    const float* xr = rows + f * rs;
-    float re[3] = {0.f, 0.f, 0.f}, im[3] = {0.f, 0.f, 0.f};
-    TapChunk ta, tb;
-    float xa[4], xb[4];
-    load_taps(ta, gf);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) xa[j] = xr[j];
-    for (int n = 0; n < n_fft; n += 8) {   // n_fft is a power of two >= 16
-        load_taps(tb, gf + (n + 4) * XQ_BPO);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) xb[j] = xr[n + 4 + j];
-        apply_taps(ta, xa, re, im);
-        const int nn = (n + 8 < n_fft) ? n + 8 : 0;   // last prefetch wraps to a valid address, result unused
-        load_taps(ta, gf + nn * XQ_BPO);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) xa[j] = xr[nn + j];
-        apply_taps(tb, xb, re, im);
+}
+
+// MAXFFT bounds the instantiated octave sizes (VQT: 128, CQT: 256): the A operand's registers set the kernel's VGPR
+// budget, and the VQT kernel should keep two workgroups per CU so that one wave stages while another multiplies.
+template <int MAXFFT>
+__global__ void __launch_bounds__(256, MAXFFT <= 128 ? 2 : 1) xqt_filter_kernel(FbArgs P) {
+    extern __shared__ __attribute__((aligned(16))) float fbl[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int clip = blockIdx.x / P.blocks_per_clip, tile_base = (blockIdx.x - clip * P.blocks_per_clip) * P.tpb;
+    float* lw = fbl + wid * P.wave_floats;
+    for (int i = 0; i < P.nruns; ++i) {
+        const FbRun r = P.run[i];
+        if (r.wave != wid) continue;
+        switch (P.L.n_fft[r.oct]) {
+            case 16: fb_run<16>(P, r, clip, tile_base, lw, lane); break;
+            case 32: fb_run<32>(P, r, clip, tile_base, lw, lane); break;
+            case 64: fb_run<64>(P, r, clip, tile_base, lw, lane); break;
+            case 128: fb_run<128>(P, r, clip, tile_base, lw, lane); break;
+            default:
+                if constexpr (MAXFFT > 128) fb_run<256>(P, r, clip, tile_base, lw, lane);
+                break;
+        }
     }
-    const int t = f0 + f;
-    if (t >= n_frames) return;
-    const int k0 = XQ_BINS - XQ_BPO * (oct + 1) + g * 3;
-    float* o = out + ((size_t)clip * XQ_BINS + k0) * n_frames + t;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) o[(size_t)k * n_frames] = logf(sqrtf(re[k] * re[k] + im[k] * im[k]) + 1e-9f);
+}
+
+// Host: distribute the (octave, tile) items of one block over its 4 waves.  Whole octaves first (longest processing time
+// first, cost = MFMAs = tiles * n_fft / 2), then single tiles move from the most to the least loaded wave while that
+// lowers the maximum.  VQT: loads 320 / 320 / 352 / 320 of 1312 (93 % balanced).
+static int fb_schedule(const int* n_fft, int tpb, FbRun* runs) {
+    int load[4] = {0, 0, 0, 0};
+    int owner[XQ_OCT][FB_TPB];
+    int order[XQ_OCT];
+    for (int i = 0; i < XQ_OCT; ++i) order[i] = i;
+    std::stable_sort(order, order + XQ_OCT, [&](int x, int y) { return n_fft[x] > n_fft[y]; });
+    for (int oi = 0; oi < XQ_OCT; ++oi) {
+        const int o = order[oi];
+        int w = 0;
+        for (int v = 1; v < 4; ++v)
+            if (load[v] < load[w]) w = v;
+        for (int t = 0; t < tpb; ++t) owner[o][t] = w;
+        load[w] += tpb * (n_fft[o] / 2);
+    }
+    for (int iter = 0; iter < 64; ++iter) {
+        int hi = 0, lo = 0;
+        for (int v = 1; v < 4; ++v) { if (load[v] > load[hi]) hi = v; if (load[v] < load[lo]) lo = v; }
+        int best_o = -1, best_t = -1;
+        for (int o = 0; o < XQ_OCT; ++o)          // the cheapest tile of `hi` whose move lowers the maximum
+            for (int t = tpb - 1; t >= 0; --t)
+                if (owner[o][t] == hi && load[lo] + n_fft[o] / 2 < load[hi] && (best_o < 0 || n_fft[o] < n_fft[best_o])) { best_o = o; best_t = t; }
+        if (best_o < 0) break;
+        owner[best_o][best_t] = lo;
+        load[hi] -= n_fft[best_o] / 2;
+        load[lo] += n_fft[best_o] / 2;
+    }
+    int n = 0;
+    for (int w = 0; w < 4; ++w)
+        for (int oi = 0; oi < XQ_OCT; ++oi) {
+            const int o = order[oi];
+            for (int t = 0; t < tpb;) {
+                if (owner[o][t] != w) { ++t; continue; }
+                int e = t;
+                while (e < tpb && owner[o][e] == w) ++e;
+                runs[n++] = FbRun{(unsigned char)w, (unsigned char)o, (unsigned char)t, (unsigned char)(e - t)};
+                t = e;
+            }
+        }
+    return n;
 }
 
 }  // namespace zns
@@ -482,6 +619,7 @@ int zns_xqt_stages_f32(const float* wav, int n_clips, int n_samples, int sample_
         L.n_fft[i] = b->n_fft[i];
         L.hop[i] = b->hop[i];
         L.off[i] = b->off[i];
+        L.vec[i] = 0;
         if (i > 0) {
             L.y[i] = pyr + (size_t)n_clips * off[i];
             L.stride[i] = (long long)(((size_t)len[i] + 3) / 4 * 4);
@@ -492,7 +630,9 @@ int zns_xqt_stages_f32(const float* wav, int n_clips, int n_samples, int sample_
     // their own (no recomputed halo where 7/8 of the taps are), the four small ones fused (their launches are
     // latency-bound: 6.5 us each for a 32-clip batch).  ZNS_XQT_PLAN="n1,n2,.." overrides the grouping (tuning aid).
     if (stages & 1) {
-        int plan[XQ_OCT] = {1, 1, 1, 4}, nplan = 4;
+        // big batches: one launch per level (the fused tail recomputes halos and runs few blocks); small ones: fused tail
+        int plan[XQ_OCT] = {1, 1, 1, 4, 1, 1, 1}, nplan = 4;
+        if (n_clips >= 256) { nplan = 7; for (int i = 0; i < 7; ++i) plan[i] = 1; }
         if (const char* e = getenv("ZNS_XQT_PLAN")) {
             nplan = 0;
             int tot = 0;
@@ -533,12 +673,41 @@ int zns_xqt_stages_f32(const float* wav, int n_clips, int n_samples, int sample_
         }
     }
     if (!(stages & 2)) return ZNS_OK;
+    for (int i = 0; i < XQ_OCT; ++i) L.vec[i] = (L.stride[i] % 4 == 0) && ((uintptr_t)L.y[i] % 16 == 0);
     const int n_frames = zns_xqt_frames(n_samples);
+    FbArgs F{};
+    F.L = L;
+    F.fira = b->fira;
+    for (int i = 0; i < XQ_OCT; ++i) F.offa[i] = b->offa[i];
+    F.n_frames = n_frames;
+    F.tiles = (n_frames + 31) / 32;
+    // tiles per block: 4 amortise an octave's A-operand load over a run of tiles; small batches take fewer so that the
+    // launch still covers the chip (32 clips x 20 tiles: 640 single-tile blocks instead of 160 latency-bound ones)
+    F.tpb = FB_TPB;
+    while (F.tpb > 1 && (long long)n_clips * ((F.tiles + F.tpb - 1) / F.tpb) < 4 * 256) F.tpb /= 2;
+    F.blocks_per_clip = (F.tiles + F.tpb - 1) / F.tpb;
+    F.nruns = fb_schedule(b->n_fft, F.tpb, F.run);
+    F.out = out;
+    int wf = 0;   // floats of one wave's staging region: the largest segment image over the octaves
+    for (int i = 0; i < XQ_OCT; ++i) {
+        const int nf = b->n_fft[i], hp = b->hop[i];
+        const int need = hp >= nf ? 32 * (nf + 1) : (31 * hp + nf) + (31 * hp + nf) / hp + 1;
+        wf = std::max(wf, need);
+    }
+    F.wave_floats = (wf + 3) / 4 * 4;
+    const size_t lds = (size_t)4 * F.wave_floats * sizeof(float);
     int max_fft = 0;
     for (int i = 0; i < XQ_OCT; ++i) max_fft = std::max(max_fft, b->n_fft[i]);
-    const size_t lds = (size_t)XQ_FPB * (max_fft + 1) * sizeof(float);
-    hipLaunchKernelGGL(xqt_filter_kernel, dim3((n_frames + XQ_FPB - 1) / XQ_FPB, XQ_OCT, n_clips), dim3(64 * XQ_GRP), lds, st, L, b->fir,
-                       n_frames, out);
+    static bool lds_set[2][ZNS_MAX_DEVICES] = {};
+    const int big = max_fft > 128 ? 1 : 0;
+    if (!lds_set[big][current_device_slot()]) {
+        ZNS_HIP(hipFuncSetAttribute(big ? (const void*)xqt_filter_kernel<256> : (const void*)xqt_filter_kernel<128>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        lds_set[big][current_device_slot()] = true;
+    }
+    const dim3 grid((unsigned)((size_t)n_clips * F.blocks_per_clip));
+    if (big) hipLaunchKernelGGL(xqt_filter_kernel<256>, grid, dim3(256), lds, st, F);
+    else hipLaunchKernelGGL(xqt_filter_kernel<128>, grid, dim3(256), lds, st, F);
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
 }
