@@ -207,6 +207,34 @@ def test_generate_xqt_batch_and_errors():
 
 
 @pytest.mark.gpu
+def test_generate_xqt_launch_plans_agree_bitwise():
+    """The launch plan depends on the batch size (one decimation launch per level vs a fused tail; 1, 2 or 4 frame tiles
+    per filter-bank workgroup) and on pointer alignment (16-byte staging vs element-wise): every plan runs the same
+    arithmetic in the same order, so the same clip must come out bit for bit the same whatever batch it travels in,
+    whether or not its rows are 16-byte aligned, and whether the two stages run in one call or two."""
+    from zeronotesamba_amd.processing.input_rep import generate_XQT_batch
+    g = torch.Generator().manual_seed(7)
+    n = 40000
+    y = (0.1 * torch.randn(300, n + 1, generator=g)).cuda()
+    big = generate_XQT_batch(y[:, :n].contiguous(), 16000, "vqt")                 # >= 256 clips: per-level plan, 4-tile blocks
+    for k in (1, 5, 40):
+        small = generate_XQT_batch(y[:k, :n].contiguous(), 16000, "vqt")          # fused tail, fewer tiles per block
+        assert torch.equal(small, big[:k]), k
+    flat = y[:3].reshape(-1)
+    odd = flat[1:1 + n].reshape(1, n)                                             # a view whose data pointer is 4 bytes off 16
+    assert odd.data_ptr() % 16 == 4
+    ref = generate_XQT_batch(odd.clone(), 16000, "vqt")
+    assert torch.equal(generate_XQT_batch(odd, 16000, "vqt"), ref)
+    out = torch.empty_like(big[:5])
+    generate_XQT_batch(y[:5, :n].contiguous(), 16000, "vqt", out=out, stages=1)   # pyramid only ...
+    generate_XQT_batch(y[:5, :n].contiguous(), 16000, "vqt", out=out, stages=2)   # ... then the filter bank on it
+    assert torch.equal(out, big[:5])
+    odd_len = generate_XQT_batch(y[:2, :n - 3].contiguous(), 16000, "cqt")        # rows not a multiple of 4, CQT (n_fft 256)
+    ref = vqt_ref.generate_XQT(y[1, :n - 3].cpu().numpy(), 16000, "cqt")
+    assert lin_err(odd_len[1].cpu().numpy(), ref) < 1e-5
+
+
+@pytest.mark.gpu
 def test_generate_xqt_linearity_at_full_size():
     """Size-independent property at BASELINE config 2 size: 32 clips x 160 000 samples."""
     from zeronotesamba_amd.processing.input_rep import generate_XQT_batch

@@ -36,7 +36,11 @@ def cpu_oracle(n_clips=2):
 
 
 if __name__ == "__main__":
-    for n, it in ((32, 50), (512, 10), (4096, 3)):
+    sizes = ((32, 50), (512, 10), (4096, 3))
+    if "--only" in sys.argv:
+        only = int(sys.argv[sys.argv.index("--only") + 1])
+        sizes = tuple(x for x in sizes if x[0] == only)
+    for n, it in sizes:
         print(json.dumps(run(n, it)))
     if "--cpu" in sys.argv:
         print(json.dumps(cpu_oracle()))

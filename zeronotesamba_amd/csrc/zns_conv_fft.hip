@@ -41,15 +41,6 @@ __device__ __forceinline__ void spec_store(__amdgpu_buffer_rsrc_t rs, unsigned v
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, 0);
 }
 
-__device__ __forceinline__ void twiddle_init(float2* tw) {
-    // tw[k] = (cos, sin)(2 pi k / 64), filled by the first 64 threads
-    if (threadIdx.x < FN) {
-        float s, c;
-        sincospif((float)threadIdx.x / 32.0f, &s, &c);
-        tw[threadIdx.x] = make_float2(c, s);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // Windows are addressed by ONE flattened index per sample, q = (c * H + h) * NB + b = c * P + p: the spectrum planes
 // S[n][slot][C][P] and the activation rows x[n][C][H][T] are both contiguous in it, so a block takes 256 consecutive
@@ -350,9 +341,6 @@ __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__
 __global__ void __launch_bounds__(256) pack_freq_weights_kernel(Ptr2 w, float* __restrict__ dst, int cin_c, int cout_c,
                                                                 int kh, int kw, int cob_sz, int ck, int mt, int wm_n,
                                                                 int transposed, long long per_wf, int nbr) {
-    __shared__ float2 tw[FN];
-    twiddle_init(tw);
-    __syncthreads();
     const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= per_wf * nbr) return;
     const int br = (int)(o / per_wf);
@@ -369,38 +357,29 @@ __global__ void __launch_bounds__(256) pack_freq_weights_kernel(Ptr2 w, float* _
     const int cob = (int)q;
     const int co = cob * cob_sz + (wm * mt + m) * 32 + i;
     const int ci = cc * ck + 2 * cp + h;
-    float wt[25];
+    // G[f] = sum_s W[s] e^{+2 pi i f s / 64} = conj(DFT_64(W zero padded)[f]): one register FFT per thread (the first
+    // version summed 32 x kw twiddle products through LDS: 1600 FMAs and 800 LDS reads per thread)
+    float x[FN];
     if (!transposed) {
         const float* wr = w.p[br] + (((size_t)co * cin_c + ci) * kh + tap) * kw;                     // W[co][ci][tap][s]
 #pragma unroll
-        for (int s = 0; s < 25; ++s) wt[s] = s < kw ? wr[s] : 0.f;
+        for (int s = 0; s < FN; ++s) x[s] = (s < 25 && s < kw) ? wr[s] : 0.f;
     } else {
         // original tensor [cout_o = cin_c][cin_o = cout_c][kh][kw]; flipped in both kernel axes
         const float* wr = w.p[br] + (((size_t)ci * cout_c + co) * kh + (kh - 1 - tap)) * kw;
 #pragma unroll
-        for (int s = 0; s < 25; ++s) wt[s] = s < kw ? wr[kw - 1 - s] : 0.f;
+        for (int s = 0; s < FN; ++s) x[s] = (s < 25 && s < kw) ? wr[kw - 1 - s] : 0.f;
     }
+    float sr[FF], si[FF];
+    rfft64(x, sr, si);
     float* d = dst + (size_t)br * FS * per_wf + off;
-    {
-        float g0 = 0.f, g32 = 0.f;
+    d[0] = sr[0];                                   // G(0)
+    d[per_wf] = si[0];                              // G(32), real
+    d[2 * per_wf] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 25; ++s) {   // taps beyond kw are zero
-            g0 += wt[s];
-            g32 += (s & 1) ? -wt[s] : wt[s];
-        }
-        d[0] = g0;
-        d[per_wf] = g32;
-        d[2 * per_wf] = 0.f;
-    }
     for (int f = 1; f < FF; ++f) {
-        float gr = 0.f, gi = 0.f;
-#pragma unroll
-        for (int s = 0; s < 25; ++s) {
-            const float2 t = tw[(f * s) & (FN - 1)];
-            gr = fmaf(wt[s], t.x, gr);
-            gi = fmaf(wt[s], t.y, gi);
-        }
         float* df = d + (size_t)(3 * f) * per_wf;
+        const float gr = sr[f], gi = -si[f];
         df[0] = gr;
         df[per_wf] = gi;
         df[2 * per_wf] = gr + gi;
@@ -408,11 +387,8 @@ __global__ void __launch_bounds__(256) pack_freq_weights_kernel(Ptr2 w, float* _
 }
 
 // slab [br*FS + 3f+t][ks][tap][cout][cin] (R1 = dzr(x)xr, R2 = dzi(x)xi, R3 = (dzr-dzi)(x)(xr+xi)) -> dW[co][ci][tap][s]
-__global__ void wgrad_spec_reduce_kernel(const float* __restrict__ slab, MPtr2 dw, int KS, int cout, int cin, int kh,
-                                         int kw, int accumulate, int nbr) {
-    __shared__ float2 tw[FN];
-    twiddle_init(tw);
-    __syncthreads();
+__global__ void __launch_bounds__(128) wgrad_spec_reduce_kernel(const float* __restrict__ slab, MPtr2 dw, int KS, int cout,
+                                                                int cin, int kh, int kw, int accumulate, int nbr) {
     const long long per = (long long)cout * cin * kh;
     const long long total = per * nbr;
     const size_t per_ks = (size_t)kh * cout * cin;
@@ -425,6 +401,7 @@ __global__ void wgrad_spec_reduce_kernel(const float* __restrict__ slab, MPtr2 d
         const int tap = (int)(e / cout);
         const size_t eoff = ((size_t)tap * cout + co) * cin + ci;
         float cr[FF], cim[FF];
+#pragma unroll
         for (int f = 0; f < FF; ++f) {
             float r1 = 0.f, r2 = 0.f, r3 = 0.f;
             const float* sp = slab + ((size_t)(br * FS + 3 * f) * KS) * per_ks + eoff;
@@ -436,18 +413,13 @@ __global__ void wgrad_spec_reduce_kernel(const float* __restrict__ slab, MPtr2 d
             if (f == 0) { cr[0] = r1; cim[0] = r2; }              // DC and Nyquist, both real
             else { cr[f] = r1 + r2; cim[f] = r3 - r1 + r2; }       // conj(dz) * x
         }
+        // dW[s] = (1/64) sum_f C[f] e^{+2 pi i f s / 64} (C Hermitian): the inverse real FFT, lags 0 .. kw-1 kept
+        float lag[FN];
+        irfft64(cr, cim, lag);
         float* d = dw.p[br] + (((size_t)co * cin + ci) * kh + tap) * kw;
-        for (int s = 0; s < kw; ++s) {
-            float acc = 0.f;
 #pragma unroll
-            for (int f = 1; f < FF; ++f) {
-                const float2 t = tw[(f * s) & (FN - 1)];
-                acc = fmaf(cr[f], t.x, acc);
-                acc = fmaf(-cim[f], t.y, acc);
-            }
-            const float r = (cr[0] + ((s & 1) ? -cim[0] : cim[0]) + 2.0f * acc) * (1.0f / FN);
-            d[s] = accumulate ? d[s] + r : r;
-        }
+        for (int s = 0; s < 25; ++s)
+            if (s < kw) d[s] = accumulate ? d[s] + lag[s] : lag[s];
     }
 }
 
