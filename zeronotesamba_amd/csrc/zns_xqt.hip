@@ -348,8 +348,8 @@ struct XqtLevels {
 // signal segment into its OWN LDS region (no workgroup barrier anywhere): element u of the segment lives at
 // u + u / hopL (hopL = min(hop, n_fft): one pad word per frame step), so lane j's operand (frame j, tap c) sits at
 // j (hopL + 1) + c + c / hopL -- an odd lane stride for every octave: conflict free.
-constexpr int FB_TPB = 4;          // tiles of 32 frames per block (fewer for small batches: see zns_xqt_stages_f32)
-constexpr int FB_MAXRUN = 32;
+constexpr int FB_TPB = 8;          // most tiles of 32 frames per block (fewer for small batches: see zns_xqt_stages_f32)
+constexpr int FB_MAXRUN = 48;
 
 struct FbRun {
     unsigned char wave, oct, tile0, ntile;
@@ -536,7 +536,7 @@ static int fb_schedule(const int* n_fft, int tpb, FbRun* runs) {
                 if (owner[o][t] != w) { ++t; continue; }
                 int e = t;
                 while (e < tpb && owner[o][e] == w) ++e;
-                runs[n++] = FbRun{(unsigned char)w, (unsigned char)o, (unsigned char)t, (unsigned char)(e - t)};
+                if (n < FB_MAXRUN) runs[n++] = FbRun{(unsigned char)w, (unsigned char)o, (unsigned char)t, (unsigned char)(e - t)};
                 t = e;
             }
         }
@@ -684,6 +684,7 @@ int zns_xqt_stages_f32(const float* wav, int n_clips, int n_samples, int sample_
     // tiles per block: 4 amortise an octave's A-operand load over a run of tiles; small batches take fewer so that the
     // launch still covers the chip (32 clips x 20 tiles: 640 single-tile blocks instead of 160 latency-bound ones)
     F.tpb = FB_TPB;
+    if (const char* e = getenv("ZNS_XQT_TPB")) F.tpb = std::max(1, std::min(FB_TPB, atoi(e)));   // tuning aid
     while (F.tpb > 1 && (long long)n_clips * ((F.tiles + F.tpb - 1) / F.tpb) < 4 * 256) F.tpb /= 2;
     F.blocks_per_clip = (F.tiles + F.tpb - 1) / F.tpb;
     F.nruns = fb_schedule(b->n_fft, F.tpb, F.run);
