@@ -155,6 +155,11 @@ int zns_bce_f32(const float* out, const float* target, size_t n, float* loss, fl
 int zns_adam_step_f32(float* p, const float* g, float* m, float* v, size_t n,
                       float lr, float beta1, float beta2, float eps, int step, float grad_scale,
                       void* stream);
+/* The same update for a list of tensors in ONE launch (torch.optim.Adam over model.parameters(): 36 tensors for
+ * Pretext_CNN).  table: DEVICE array of n_tensors records {float* p; const float* g; float* m; float* v; uint64 n}
+ * (five 8-byte fields); max_n = the largest n.  All tensors share lr, betas, eps and the step count. */
+int zns_adam_multi_f32(const void* table, int n_tensors, size_t max_n, float lr, float beta1, float beta2,
+                       float eps, int step, float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------ generate_XQT (input_rep.py:11-57)
  * wav: [n_clips, n_samples] fp32 @16 kHz; out: [n_clips, 96, 1 + n_samples/256] = log(|XQT| + 1e-9).

@@ -45,6 +45,8 @@ SIGNATURES = {
     "zns_bce_f32": (C.c_int, [c_fp, c_fp, C.c_size_t, c_fp, c_fp, C.c_float, c_fp]),
     "zns_adam_step_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_int, C.c_float, c_fp]),
+    "zns_adam_multi_f32": (C.c_int, [c_fp, C.c_int, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
+                                     C.c_float, c_fp]),
     "zns_xqt_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "zns_xqt_frames": (C.c_int, [C.c_int]),
     "zns_xqt_host_bank": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_size_t,

@@ -35,7 +35,7 @@ using namespace zns;
 extern "C" {
 
 const char* zns_last_error(void) { return g_err; }
-int zns_version(void) { return 104; }   // 101: dzspec_out / dzspec, 102: stem mix + RMS gate, 103: NT-Xent workspace (any batch size), 104: packed-weight hand-off, staged xqt
+int zns_version(void) { return 104; }   // 101: dzspec_out / dzspec, 102: stem mix + RMS gate, 103: NT-Xent workspace (any batch size), 104: packed-weight hand-off, staged xqt, multi-tensor Adam
 int zns_set_impl(int impl) {
     const int prev = g_impl;
     g_impl = impl;

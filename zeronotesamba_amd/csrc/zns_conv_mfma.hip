@@ -38,6 +38,17 @@ using D5 = ConvCfg<256, 128, 3, 19, 8, 4, 2, 1, 1, 4, 2, 4, 1, 1>;
 using D6 = ConvCfg<256, 256, 5, 21, 8, 4, 2, 1, 2, 4, 1, 2, 1, 1>;
 using D7 = ConvCfg<128, 256, 1, 23, 1, 2, 1, 1, 4, 1, 2, 2, 1, 1>;
 using D8 = ConvCfg<128, 128, 1, 25, 1, 1, 1, 1, 4, 1, 2, 4, 1, 1>;
+// cv7 / cv8 with 32-column workgroups (4 waves) for small launches: the batch-of-one fine-tune step (epochs.py:48-63,
+// T = 1876) gives the 64-column tiles only 60 workgroups for 256 CUs.  Same packed-weight layout (COB, CK, MT, WM).
+using F7s = ConvCfg<256, 128, 1, 23, 1, 1, 1, 1, 4, 1, 1, 4, 1, 0>;
+using F8s = ConvCfg<128, 128, 1, 25, 1, 1, 1, 1, 4, 1, 1, 4, 1, 0>;
+using D7s = ConvCfg<128, 256, 1, 23, 1, 2, 1, 1, 4, 1, 1, 2, 1, 1>;
+using D8s = ConvCfg<128, 128, 1, 25, 1, 1, 1, 1, 4, 1, 1, 4, 1, 1>;
+// true when the wide tiles would leave most CUs without a workgroup
+template <class Wide>
+static bool few_workgroups(const ConvArgs& a) {
+    return (long long)a.nbr * a.B * ceil_div(a.T, Wide::WB) * (Wide::COUT / Wide::COB) * (Wide::H / Wide::RB) < 160;
+}
 //                CIN COUT KH KW  H  MT NS WMW WQ R
 using W2 = WgCfg<64, 64, 7, 13, 96, 2, 4, 1, 8, 1>;
 using W3 = WgCfg<64, 128, 5, 15, 32, 2, 4, 2, 4, 1>;
@@ -165,8 +176,12 @@ int mfma_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, uin
         case 4: return launch_core<F4>(a, A, w, 0, wpk, ws, ws_bytes, st);
         case 5: return launch_core<F5>(a, A, w, 0, wpk, ws, ws_bytes, st);
         case 6: return launch_core<F6>(a, A, w, 0, wpk, ws, ws_bytes, st);
-        case 7: return launch_core<F7>(a, A, w, 0, wpk, ws, ws_bytes, st);
-        case 8: return launch_core<F8>(a, A, w, 0, wpk, ws, ws_bytes, st);
+        case 7:
+            if (few_workgroups<F7>(a)) return launch_core<F7s>(a, A, w, 0, wpk, ws, ws_bytes, st);
+            return launch_core<F7>(a, A, w, 0, wpk, ws, ws_bytes, st);
+        case 8:
+            if (few_workgroups<F8>(a)) return launch_core<F8s>(a, A, w, 0, wpk, ws, ws_bytes, st);
+            return launch_core<F8>(a, A, w, 0, wpk, ws, ws_bytes, st);
     }
     return ZNS_ERR_ARG;
 }
@@ -186,8 +201,12 @@ int mfma_dgrad(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, const floa
         case 4: return launch_core<D4>(a, A, w, 1, wpk, ws, ws_bytes, st);
         case 5: return launch_core<D5>(a, A, w, 1, wpk, ws, ws_bytes, st);
         case 6: return launch_core<D6>(a, A, w, 1, wpk, ws, ws_bytes, st);
-        case 7: return launch_core<D7>(a, A, w, 1, wpk, ws, ws_bytes, st);
-        case 8: return launch_core<D8>(a, A, w, 1, wpk, ws, ws_bytes, st);
+        case 7:
+            if (few_workgroups<D7>(a)) return launch_core<D7s>(a, A, w, 1, wpk, ws, ws_bytes, st);
+            return launch_core<D7>(a, A, w, 1, wpk, ws, ws_bytes, st);
+        case 8:
+            if (few_workgroups<D8>(a)) return launch_core<D8s>(a, A, w, 1, wpk, ws, ws_bytes, st);
+            return launch_core<D8>(a, A, w, 1, wpk, ws, ws_bytes, st);
     }
     return ZNS_ERR_ARG;
 }

@@ -280,6 +280,49 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// Multi-tensor form: one launch for a list of parameter tensors (the module path hands torch-style per-parameter
+// state to the optimizer: 36 tensors of 1 .. 6.9 M elements).  blockIdx.y = tensor, blockIdx.x strides over it.
+struct AdamSlot {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    unsigned long long n;
+};
+__global__ void adam_multi_kernel(const AdamSlot* __restrict__ tab, float b1, float b2, float eps, float step_size,
+                                  float sqrt_bc2, float grad_scale) {
+    const AdamSlot s = tab[blockIdx.y];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const bool aligned = (((uintptr_t)s.p | (uintptr_t)s.g | (uintptr_t)s.m | (uintptr_t)s.v) & 15) == 0;
+    const size_t n4 = aligned ? s.n / 4 : 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pp = reinterpret_cast<float4*>(s.p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(s.g)[i];
+        float4 mm = reinterpret_cast<float4*>(s.m)[i];
+        float4 vv = reinterpret_cast<float4*>(s.v)[i];
+        float* pf = &pp.x; const float* gf = &gg.x; float* mf = &mm.x; float* vf = &vv.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = gf[k] * grad_scale;
+            mf[k] = mf[k] + (gk - mf[k]) * (1.f - b1);
+            vf[k] = vf[k] * b2 + (1.f - b2) * gk * gk;
+            const float denom = sqrtf(vf[k]) / sqrt_bc2 + eps;
+            pf[k] = pf[k] - step_size * (mf[k] / denom);
+        }
+        reinterpret_cast<float4*>(s.p)[i] = pp;
+        reinterpret_cast<float4*>(s.m)[i] = mm;
+        reinterpret_cast<float4*>(s.v)[i] = vv;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < s.n; i += stride) {
+        const float gk = s.g[i] * grad_scale;
+        const float mk = s.m[i] + (gk - s.m[i]) * (1.f - b1);
+        const float vk = s.v[i] * b2 + (1.f - b2) * gk * gk;
+        s.m[i] = mk;
+        s.v[i] = vk;
+        s.p[i] = s.p[i] - step_size * (mk / (sqrtf(vk) / sqrt_bc2 + eps));
+    }
+}
+
 // ------------------------------------------------------------------ shift batching (pretext.py:308-318)
 __global__ void shift_gather_kernel(const float* __restrict__ bank, int bank_T, const int32_t* __restrict__ clip,
                                     const int32_t* __restrict__ start, int n_items, int T,
@@ -461,6 +504,21 @@ int zns_adam_step_f32(float* p, const float* g, float* m, float* v, size_t n, fl
     const int blocks = (int)(want > 4096 ? 4096 : (want ? want : 1));
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, beta1, beta2, eps,
                        step_size, sqrt_bc2, grad_scale, aligned);
+    ZNS_LAUNCH_CHECK();
+    return ZNS_OK;
+}
+
+int zns_adam_multi_f32(const void* table, int n_tensors, size_t max_n, float lr, float beta1, float beta2, float eps,
+                       int step, float grad_scale, void* stream) {
+    ZNS_CHECK_ARG(step >= 1, "adam: step must be >= 1");
+    ZNS_CHECK_ARG(table != nullptr && n_tensors >= 1 && n_tensors <= 65535, "adam_multi: bad table (n_tensors=%d)", n_tensors);
+    if (max_n == 0) return ZNS_OK;
+    const double bc1 = 1.0 - pow((double)beta1, step);
+    const double bc2 = 1.0 - pow((double)beta2, step);
+    const size_t want = (max_n / 4 + 255) / 256;
+    const int bx = (int)(want > 2048 ? 2048 : (want ? want : 1));
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(bx, n_tensors), dim3(256), 0, (hipStream_t)stream, (const AdamSlot*)table,
+                       beta1, beta2, eps, (float)((double)lr / bc1), (float)sqrt(bc2), grad_scale);
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
 }
