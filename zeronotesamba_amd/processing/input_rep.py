@@ -20,10 +20,12 @@ _MODES = {"vqt": _lib.ZNS_MODE_VQT, "cqt": _lib.ZNS_MODE_CQT}
 
 
 def generate_XQT_batch(signals: torch.Tensor, sample_rate: int, mode: str, out: torch.Tensor = None,
-                       stages: int = 3) -> torch.Tensor:
+                       stages: int = 3, ws: torch.Tensor = None) -> torch.Tensor:
     """signals: float32 [n_clips, n_samples] on a ROCm device -> float32 [n_clips, 96, 1 + n_samples//256].
     out: optional preallocated result (steady-state pipelines reuse it).  stages: 3 = the whole transform; 1 / 2 run
-    the decimation pyramid / the filter bank alone on the shared workspace (bench.py times them separately)."""
+    the decimation pyramid / the filter bank alone on the shared workspace (bench.py times them separately).
+    ws: optional caller-owned uint8 workspace of zns_xqt_workspace_bytes (a pipeline that overlaps two batches on two
+    streams gives each its own; the default is one grow-only buffer per device)."""
     if mode not in _MODES:
         raise Exception("Mode can only be vqt or cqt!")
     _ops.require_device(signals, "generate_XQT input")
@@ -37,7 +39,8 @@ def generate_XQT_batch(signals: torch.Tensor, sample_rate: int, mode: str, out: 
         out = torch.empty((n_clips, 96, T), dtype=torch.float32, device=x.device)
     elif tuple(out.shape) != (n_clips, 96, T) or out.dtype != torch.float32 or out.device != x.device or not out.is_contiguous():
         raise ValueError(f"generate_XQT_batch: out must be a contiguous float32 [{n_clips}, 96, {T}] tensor on {x.device}")
-    ws = _ops.workspace(L.zns_xqt_workspace_bytes(n_clips, n, _MODES[mode]), x.device, slot=1)
+    if ws is None:
+        ws = _ops.workspace(L.zns_xqt_workspace_bytes(n_clips, n, _MODES[mode]), x.device, slot=1)
     with _ops.on_device(x):       # the FIR bank is cached per device
         rc = L.zns_xqt_stages_f32(x.data_ptr(), n_clips, n, int(sample_rate), _MODES[mode], out.data_ptr(),
                                   ws.data_ptr(), ws.numel(), int(stages), _ops.stream_ptr(x.device))
