@@ -205,7 +205,18 @@ def measure_module_path(dev, iters: int = 10) -> dict:
         loss.backward()
         opt.step()
 
-    return {"module_path_ms_per_step": _timed(step, iters, 3)}
+    out = {"module_path_ms_per_step": _timed(step, iters, 3)}
+    # the validation step of pretext.val_epoch (:527-592): eval mode, no_grad, same batch -- nothing is saved for a
+    # backward pass and the packed frequency weights are reused from call to call
+    model.eval()
+
+    def val_step():
+        with torch.no_grad():
+            a, p = model(anchors, postves)
+            crit(a, p)
+
+    out["val_batch_ms"] = _timed(val_step, iters, 3)
+    return out
 
 
 XQT_SAMPLES = 160000                     # 10 s at 16 kHz (BASELINE configs[1])

@@ -319,12 +319,16 @@ def test_packed_weights_are_cached_until_the_weights_change(monkeypatch):
     n = len(calls)
     val_epoch(m, loader, crit, None)
     assert len(calls) == n                                      # a whole validation epoch without a single pack launch
-    # a training step changes the weights: forward AND backward-data operands are rebuilt, results follow the new weights
+    # with gradients ON the cache is never trusted (a write through `.data` does not bump the version counter): every call
+    # repacks; a training step changes the weights and the next no-grad forward follows them
     for make_opt in (lambda ps: torch.optim.Adam(ps, lr=1e-5), lambda ps: Adam(ps, lr=1e-5)):
         opt = make_opt(m.parameters())
+        n = len(calls)
         a, p = m(anc, pos)
+        assert len(calls) == n + 7
         loss, _, _ = crit(a, p)
         loss.backward()
+        assert len(calls) == n + 14 and sum(calls[n + 7:]) == 7       # the seven backward-data operands
         opt.step()
         n = len(calls)
         with torch.no_grad():
@@ -332,6 +336,14 @@ def test_packed_weights_are_cached_until_the_weights_change(monkeypatch):
             assert len(calls) == n + 7
             ar, pr = fresh({k: v.detach().cpu() for k, v in m.state_dict().items()})(anc, pos)
         assert torch.equal(a4, ar) and torch.equal(p4, pr) and not torch.equal(a4, a1)
+    # the documented blind spot and its remedy: a `.data` write between two no-grad forwards needs invalidate_packed
+    from zeronotesamba_amd import _ops
+    with torch.no_grad():
+        m.anchor.pretrained.cv4.weight.data.mul_(1.5)
+        _ops.invalidate_packed(m)
+        a6, p6 = m(anc, pos)
+        ar, pr = fresh({k: v.detach().cpu() for k, v in m.state_dict().items()})(anc, pos)
+    assert torch.equal(a6, ar) and torch.equal(p6, pr)
     tr = PretextTrainer(m, batch_len=B, lr=1e-5, train=False)
     x = tr.stack_inputs(loader[0][0])
     e0 = tr.evaluate(x)

@@ -93,7 +93,8 @@ def _pp(tensors: Sequence[torch.Tensor]):
     return _lib.ptr_array([t.data_ptr() for t in tensors])
 
 
-def packed_weights(li: int, transposed: bool, nbr: int, B: int, T: int, w: Sequence[torch.Tensor]) -> Optional[torch.Tensor]:
+def packed_weights(li: int, transposed: bool, nbr: int, B: int, T: int, w: Sequence[torch.Tensor],
+                   trust: bool = False) -> Optional[torch.Tensor]:
     """The kernel-order operand of layer li's weights (zns_conv2d_pack_f32), rebuilt only when a weight tensor changed.
 
     The frequency-domain kernels read 96 real operators per branch built from the DFT of the time taps (5-7x the weights:
@@ -101,7 +102,14 @@ def packed_weights(li: int, transposed: bool, nbr: int, B: int, T: int, w: Seque
     sample_script.py:46-48) call the model many times with the SAME weights, so the operand is cached: on the first
     branch's weight Parameter itself (it dies with the model), keyed by the library's layout id (layer, tile variant,
     kernel family) and the tensors' addresses, validated by their autograd version counters.  Everything in this package
-    that writes parameters through a raw pointer (the fused Adam kernels) bumps those counters."""
+    that writes parameters through a raw pointer (the fused Adam kernels) bumps those counters.
+
+    `trust`: the cached operand is only reused where the caller is NOT training (no parameter needs a gradient:
+    `torch.no_grad()` / `inference_mode` / frozen weights -- val_epoch, inference loops, PretextTrainer.evaluate); a
+    training pass rebuilds it on every call, the weights change every step anyway.  Reason: a write through `param.data`
+    (old-style manual SGD, `p.data.clamp_()`) does not bump the version counter -- the same blind spot autograd itself
+    has -- and must never train on stale weights.  Between two inference forwards such a write needs
+    `invalidate_packed(model)`."""
     name, cin, cout, kh, kw, pool = LAYERS[li]
     L = _lib.lib()
     lid = _lib.C.c_int(0)
@@ -113,7 +121,7 @@ def packed_weights(li: int, transposed: bool, nbr: int, B: int, T: int, w: Seque
         sig = tuple(t._version for t in w)
         cache = w[0].__dict__.setdefault("_zns_pack", {})
         hit = cache.get(key)
-        if hit is not None and hit[0] == sig:
+        if trust and hit is not None and hit[0] == sig:
             return hit[1]
         buf = hit[1] if hit is not None else torch.empty(nbytes // 4, dtype=torch.float32, device=w[0].device)
         same_device(w[0], w, name)
@@ -124,13 +132,20 @@ def packed_weights(li: int, transposed: bool, nbr: int, B: int, T: int, w: Seque
     return buf
 
 
+def invalidate_packed(module: torch.nn.Module) -> None:
+    """Drop every cached packed operand of `module`'s parameters (after writing weights through `.data` or a raw pointer)."""
+    for p in module.parameters():
+        p.__dict__.pop("_zns_pack", None)
+
+
 def bump_version(t: torch.Tensor) -> None:
     """Tell autograd (and packed_weights) that `t` -- and every view of it -- was written through its raw pointer."""
     torch.autograd.graph.increment_version(t)
 
 
 def conv_fwd(li: int, nbr: int, B: int, T: int, x: torch.Tensor, w: Sequence[torch.Tensor],
-             b: Sequence[torch.Tensor], drop_p: float, seed: int, want_argmax: bool, ws: torch.Tensor):
+             b: Sequence[torch.Tensor], drop_p: float, seed: int, want_argmax: bool, ws: torch.Tensor,
+             trust_packed: bool = False):
     name, cin, cout, kh, kw, pool = LAYERS[li]
     H = H_IN[li]
     y = torch.empty((nbr * B, cout, H // pool, T), dtype=torch.float32, device=x.device)
@@ -144,7 +159,7 @@ def conv_fwd(li: int, nbr: int, B: int, T: int, x: torch.Tensor, w: Sequence[tor
         if nspec:
             spec = torch.empty(nspec // 4, dtype=torch.float32, device=x.device)
     same_device(x, (*w, *b, ws), name)
-    wpk = packed_weights(li, False, nbr, B, T, w)
+    wpk = packed_weights(li, False, nbr, B, T, w, trust_packed)
     with on_device(x):
         rc = _lib.lib().zns_conv2d_fwd_f32(nbr, B, T, cin, cout, kh, kw, H, pool, x.data_ptr(), _pp(w), _pp(b),
                                            y.data_ptr(), am.data_ptr() if am is not None else None,
@@ -262,7 +277,8 @@ class StackParams:
 
 def stack_forward(x: torch.Tensor, P: StackParams, B: int, drop_p: float, seed: int, save: bool,
                   with_head: bool = True, ws_slot: int = 0):
-    """x: [nbr*B, 1, 96, T] -> (emb [nbr*B, T] or None, acts [y1..y8], argmax {layer: u8})."""
+    """x: [nbr*B, 1, 96, T] -> (emb [nbr*B, T] or None, acts [y1..y8], argmax {layer: u8}).
+    save=False is the inference form (nothing kept for a backward pass): only then are cached packed weights reused."""
     nbr = P.nbr
     T = x.shape[-1]
     with on_device(x):
@@ -271,7 +287,10 @@ def stack_forward(x: torch.Tensor, P: StackParams, B: int, drop_p: float, seed: 
     argm: Dict[int, torch.Tensor] = {}
     cur = x
     for li in range(8):
-        y, am, spec = conv_fwd(li, nbr, B, T, cur, P.conv_w[li], P.conv_b[li], drop_p, seed, save, ws)
+        # inference, or this layer's weights are frozen (loader.py:30-34): nothing updates them between calls
+        trust = not save or not any(w.requires_grad for w in P.conv_w[li])
+        y, am, spec = conv_fwd(li, nbr, B, T, cur, P.conv_w[li], P.conv_b[li], drop_p, seed, save, ws,
+                               trust_packed=trust)
         if save:
             acts.append(y)
             if am is not None:

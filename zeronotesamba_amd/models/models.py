@@ -23,18 +23,26 @@ def _fresh_seed() -> int:
     return int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
 
 
+def _apply_stack(x, nbr, B, drop_p, seed, with_head, *params):
+    """_StackFn.apply with the caller's grad mode passed in (autograd switches it off inside forward(), and
+    ctx.needs_input_grad only reflects requires_grad): under torch.no_grad() -- val_epoch, inference -- nothing is saved
+    for a backward pass and the cached packed weights are reused."""
+    return _StackFn.apply(x, nbr, B, drop_p, seed, with_head, torch.is_grad_enabled(), *params)
+
+
 class _StackFn(torch.autograd.Function):
     """nbr DS_CNN stacks (conv stack [+ head]) as one autograd node.
 
-    forward(x [nbr*B,1,96,T], nbr, B, drop_p, seed, with_head, *params) -> emb [nbr*B,T] (or h [nbr*B,128,T])
+    forward(x [nbr*B,1,96,T], nbr, B, drop_p, seed, with_head, grad_on, *params) -> emb [nbr*B,T] (or h [nbr*B,128,T])
     drop_p: dropout probability of this call (the module's `dp.p` in train mode, 0 in eval mode).
+    grad_on: torch.is_grad_enabled() at the call site (see _apply_stack).
     """
 
     @staticmethod
-    def forward(ctx, x, nbr, B, drop_p, seed, with_head, *params):
+    def forward(ctx, x, nbr, B, drop_p, seed, with_head, grad_on, *params):
         P = _ops.StackParams.from_flat(params, nbr)
-        pneeds = ctx.needs_input_grad[6:]
-        need_grad = any(pneeds)
+        pneeds = ctx.needs_input_grad[7:]
+        need_grad = any(pneeds) and bool(grad_on)
         drop_p = float(drop_p)
         emb, acts, argm = _ops.stack_forward(x, P, B, drop_p, seed, save=need_grad, with_head=with_head)
         ctx.nbr, ctx.B, ctx.with_head = nbr, B, with_head
@@ -81,7 +89,7 @@ class _StackFn(torch.autograd.Function):
                 out_grads.append(None)
             else:
                 out_grads.append(grads[i])
-        return (None, None, None, None, None, None, *out_grads)
+        return (None, None, None, None, None, None, None, *out_grads)
 
 
 def _prep_input(x: torch.Tensor, what: str) -> torch.Tensor:
@@ -141,7 +149,7 @@ class _CNN(nn.Module):
         dummy = [params[0].new_zeros(1), params[0].new_zeros(1)]  # head slots, unused when with_head=False
         drop_p = self.drop_p()
         seed = _fresh_seed() if drop_p > 0.0 else 0
-        return _StackFn.apply(x, 1, x.shape[0], drop_p, seed, False, *params, *dummy)
+        return _apply_stack(x, 1, x.shape[0], drop_p, seed, False, *params, *dummy)
 
 
 class DS_CNN(nn.Module):
@@ -168,7 +176,7 @@ class DS_CNN(nn.Module):
         x = _prep_input(x, "DS_CNN input")
         drop_p = self.pretrained.drop_p()
         seed = _fresh_seed() if drop_p > 0.0 else 0
-        return _StackFn.apply(x, 1, x.shape[0], drop_p, seed, True, *self.stack_params())
+        return _apply_stack(x, 1, x.shape[0], drop_p, seed, True, *self.stack_params())
 
 
 class Pretext_CNN(nn.Module):
@@ -198,7 +206,7 @@ class Pretext_CNN(nn.Module):
         B = anc.shape[0]
         x = torch.cat([anc, pos], dim=0)
         seed = _fresh_seed() if drop_p > 0.0 else 0
-        emb = _StackFn.apply(x, 2, B, drop_p, seed, True, *self.anchor.stack_params(),
+        emb = _apply_stack(x, 2, B, drop_p, seed, True, *self.anchor.stack_params(),
                              *self.postve.stack_params())
         return emb[:B], emb[B:]
 
