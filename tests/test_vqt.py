@@ -208,17 +208,17 @@ def test_generate_xqt_batch_and_errors():
 
 @pytest.mark.gpu
 def test_generate_xqt_launch_plans_agree_bitwise():
-    """The launch plan depends on the batch size (one decimation launch per level vs a fused tail; 1, 2 or 4 frame tiles
-    per filter-bank workgroup) and on pointer alignment (16-byte staging vs element-wise): every plan runs the same
+    """The launch plan depends on the batch size (one decimation launch per level vs a fused tail; one tile or a run of
+    tiles per filter-bank wave) and on pointer alignment (16-byte staging vs element-wise): every plan runs the same
     arithmetic in the same order, so the same clip must come out bit for bit the same whatever batch it travels in,
     whether or not its rows are 16-byte aligned, and whether the two stages run in one call or two."""
     from zeronotesamba_amd.processing.input_rep import generate_XQT_batch
     g = torch.Generator().manual_seed(7)
     n = 40000
     y = (0.1 * torch.randn(300, n + 1, generator=g)).cuda()
-    big = generate_XQT_batch(y[:, :n].contiguous(), 16000, "vqt")                 # >= 256 clips: per-level plan, 4-tile blocks
-    for k in (1, 5, 40):
-        small = generate_XQT_batch(y[:k, :n].contiguous(), 16000, "vqt")          # fused tail, fewer tiles per block
+    big = generate_XQT_batch(y[:, :n].contiguous(), 16000, "vqt")                 # >= 256 clips: per-level plan, runs of tiles
+    for k in (1, 5, 40, 70):
+        small = generate_XQT_batch(y[:k, :n].contiguous(), 16000, "vqt")          # fused tail, single tiles under 64 clips
         assert torch.equal(small, big[:k]), k
     flat = y[:3].reshape(-1)
     odd = flat[1:1 + n].reshape(1, n)                                             # a view whose data pointer is 4 bytes off 16

@@ -36,7 +36,8 @@ def cpu_oracle(n_clips=2):
 
 
 if __name__ == "__main__":
-    sizes = ((32, 50), (512, 10), (4096, 3))
+    sizes = ((32, 50), (64, 30), (128, 20), (256, 10), (512, 10), (4096, 3))
+    if "--only" not in sys.argv: sizes = (sizes[0], sizes[4], sizes[5])
     if "--only" in sys.argv:
         only = int(sys.argv[sys.argv.index("--only") + 1])
         sizes = tuple(x for x in sizes if x[0] == only)

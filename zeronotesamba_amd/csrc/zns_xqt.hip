@@ -342,30 +342,31 @@ struct XqtLevels {
 // (16 % of the FMA peak).  The accumulation order per output is n = 0, 1, 2, ... exactly as a scalar fmaf chain (an fp32
 // MFMA is bit for bit an fmaf chain), so results are identical to the kernel this replaces.
 //
-// Work split: a block owns FB_TPB consecutive 32-frame tiles of one clip; its four waves share the (octave, tile) items
-// along a host-built schedule (longest-processing-time over the octaves' MFMA counts, 64..8 per tile, then tile-level
-// rebalancing): a wave loads an octave's A operand once and walks that octave's tiles.  Every wave stages its tile's
-// signal segment into its OWN LDS region (no workgroup barrier anywhere): element u of the segment lives at
-// u + u / hopL (hopL = min(hop, n_fft): one pad word per frame step), so lane j's operand (frame j, tap c) sits at
-// j (hopL + 1) + c + c / hopL -- an odd lane stride for every octave: conflict free.
-constexpr int FB_TPB = 8;          // most tiles of 32 frames per block (fewer for small batches: see zns_xqt_stages_f32)
-constexpr int FB_MAXRUN = 48;
+// Work split: a block owns (octave, clip, 4 * tpw consecutive 32-frame tiles) and each of its four waves a run of tpw
+// tiles: a wave loads its octave's A operand once and walks its tiles; all waves of a block do the same amount of work
+// and blocks are numbered octave-major by falling n_fft, so the long items (64 MFMAs per tile) are dispatched first and
+// the 8-MFMA ones fill the tail.  (Round 2 first gave a block ALL octaves of a tile group, its waves sharing the
+// (octave, tile) items along a host-built longest-processing-time schedule: 93 % balanced on paper, but a wave walked
+// two or three octaves one exposed latency after the other -- 1.78 ms per 4096 clips against 1.69 ms, 39 us per 32 clips
+// against 23 us.)  Every wave stages its tile's signal segment into its OWN LDS region (no workgroup barrier anywhere):
+// element u of the segment lives at u + u / hopL (hopL = min(hop, n_fft): one pad word per frame step), so lane j's
+// operand (frame j, tap c) sits at j (hopL + 1) + c + c / hopL -- an odd lane stride for every octave: conflict free.
+constexpr int FB_TPW = 8;          // most tiles of 32 frames per wave (one for small batches: see zns_xqt_stages_f32)
 
 struct FbRun {
-    unsigned char wave, oct, tile0, ntile;
+    int oct, tile0, ntile;
 };
 struct FbArgs {
     XqtLevels L;
     const float* fira;
     int offa[XQ_OCT];
-    int n_frames, tiles, tpb, blocks_per_clip, nruns, wave_floats;
-    FbRun run[FB_MAXRUN];
+    int n_frames, tiles, tpw, blocks_per_clip, n_clips, wave_floats;
+    unsigned char order[XQ_OCT];       // octaves by falling n_fft
     float* out;
 };
 
 template <int NFFT>
-__device__ __forceinline__ void fb_run(const FbArgs& P, const FbRun r, int clip, int tile_base, float* __restrict__ lw,
-                                       int lane) {
+__device__ __forceinline__ void fb_run(const FbArgs& P, const FbRun r, int clip, float* __restrict__ lw, int lane) {
     const int oct = r.oct;
     const int hop = P.L.hop[oct], len = P.L.len[oct];
     const int hopL = hop < NFFT ? hop : NFFT;
@@ -434,7 +435,7 @@ __device__ __forceinline__ void fb_run(const FbArgs& P, const FbRun r, int clip,
             }
         }
     };
-    const int first = tile_base + r.tile0;
+    const int first = r.tile0;
     if (first >= P.tiles) return;
     bool pre = interior(first * 32);
     if (pre) load_tile(first * 32);
@@ -482,65 +483,20 @@ __global__ void __launch_bounds__(256, MAXFFT <= 128 ? 2 : 1) xqt_filter_kernel(
     extern __shared__ __attribute__((aligned(16))) float fbl[];
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int clip = blockIdx.x / P.blocks_per_clip, tile_base = (blockIdx.x - clip * P.blocks_per_clip) * P.tpb;
     float* lw = fbl + wid * P.wave_floats;
-    for (int i = 0; i < P.nruns; ++i) {
-        const FbRun r = P.run[i];
-        if (r.wave != wid) continue;
-        switch (P.L.n_fft[r.oct]) {
-            case 16: fb_run<16>(P, r, clip, tile_base, lw, lane); break;
-            case 32: fb_run<32>(P, r, clip, tile_base, lw, lane); break;
-            case 64: fb_run<64>(P, r, clip, tile_base, lw, lane); break;
-            case 128: fb_run<128>(P, r, clip, tile_base, lw, lane); break;
-            default:
-                if constexpr (MAXFFT > 128) fb_run<256>(P, r, clip, tile_base, lw, lane);
-                break;
-        }
+    int bid = blockIdx.x;
+    const int group = bid % P.blocks_per_clip; bid /= P.blocks_per_clip;
+    const int clip = bid % P.n_clips;
+    const FbRun r{P.order[bid / P.n_clips], (4 * group + wid) * P.tpw, P.tpw};
+    switch (P.L.n_fft[r.oct]) {
+        case 16: fb_run<16>(P, r, clip, lw, lane); break;
+        case 32: fb_run<32>(P, r, clip, lw, lane); break;
+        case 64: fb_run<64>(P, r, clip, lw, lane); break;
+        case 128: fb_run<128>(P, r, clip, lw, lane); break;
+        default:
+            if constexpr (MAXFFT > 128) fb_run<256>(P, r, clip, lw, lane);
+            break;
     }
-}
-
-// Host: distribute the (octave, tile) items of one block over its 4 waves.  Whole octaves first (longest processing time
-// first, cost = MFMAs = tiles * n_fft / 2), then single tiles move from the most to the least loaded wave while that
-// lowers the maximum.  VQT: loads 320 / 320 / 352 / 320 of 1312 (93 % balanced).
-static int fb_schedule(const int* n_fft, int tpb, FbRun* runs) {
-    int load[4] = {0, 0, 0, 0};
-    int owner[XQ_OCT][FB_TPB];
-    int order[XQ_OCT];
-    for (int i = 0; i < XQ_OCT; ++i) order[i] = i;
-    std::stable_sort(order, order + XQ_OCT, [&](int x, int y) { return n_fft[x] > n_fft[y]; });
-    for (int oi = 0; oi < XQ_OCT; ++oi) {
-        const int o = order[oi];
-        int w = 0;
-        for (int v = 1; v < 4; ++v)
-            if (load[v] < load[w]) w = v;
-        for (int t = 0; t < tpb; ++t) owner[o][t] = w;
-        load[w] += tpb * (n_fft[o] / 2);
-    }
-    for (int iter = 0; iter < 64; ++iter) {
-        int hi = 0, lo = 0;
-        for (int v = 1; v < 4; ++v) { if (load[v] > load[hi]) hi = v; if (load[v] < load[lo]) lo = v; }
-        int best_o = -1, best_t = -1;
-        for (int o = 0; o < XQ_OCT; ++o)          // the cheapest tile of `hi` whose move lowers the maximum
-            for (int t = tpb - 1; t >= 0; --t)
-                if (owner[o][t] == hi && load[lo] + n_fft[o] / 2 < load[hi] && (best_o < 0 || n_fft[o] < n_fft[best_o])) { best_o = o; best_t = t; }
-        if (best_o < 0) break;
-        owner[best_o][best_t] = lo;
-        load[hi] -= n_fft[best_o] / 2;
-        load[lo] += n_fft[best_o] / 2;
-    }
-    int n = 0;
-    for (int w = 0; w < 4; ++w)
-        for (int oi = 0; oi < XQ_OCT; ++oi) {
-            const int o = order[oi];
-            for (int t = 0; t < tpb;) {
-                if (owner[o][t] != w) { ++t; continue; }
-                int e = t;
-                while (e < tpb && owner[o][e] == w) ++e;
-                if (n < FB_MAXRUN) runs[n++] = FbRun{(unsigned char)w, (unsigned char)o, (unsigned char)t, (unsigned char)(e - t)};
-                t = e;
-            }
-        }
-    return n;
 }
 
 }  // namespace zns
@@ -681,13 +637,19 @@ int zns_xqt_stages_f32(const float* wav, int n_clips, int n_samples, int sample_
     for (int i = 0; i < XQ_OCT; ++i) F.offa[i] = b->offa[i];
     F.n_frames = n_frames;
     F.tiles = (n_frames + 31) / 32;
-    // tiles per block: 4 amortise an octave's A-operand load over a run of tiles; small batches take fewer so that the
-    // launch still covers the chip (32 clips x 20 tiles: 640 single-tile blocks instead of 160 latency-bound ones)
-    F.tpb = FB_TPB;
-    if (const char* e = getenv("ZNS_XQT_TPB")) F.tpb = std::max(1, std::min(FB_TPB, atoi(e)));   // tuning aid
-    while (F.tpb > 1 && (long long)n_clips * ((F.tiles + F.tpb - 1) / F.tpb) < 4 * 256) F.tpb /= 2;
-    F.blocks_per_clip = (F.tiles + F.tpb - 1) / F.tpb;
-    F.nruns = fb_schedule(b->n_fft, F.tpb, F.run);
+    // tiles per wave: a quarter of the clip's tiles (the A operand is loaded once per wave); batches under 64 clips take
+    // single tiles so that the launch still covers the chip (32 clips: 1280 blocks instead of 256).  Measured, kernel
+    // time of the filter bank, tpw = 1 / 5: 32 clips 23 / 29 us, 64 clips 41 / 35 us, 4096 clips 2.22 / 1.69 ms.
+    F.tpw = n_clips < 64 ? 1 : std::max(1, std::min(FB_TPW, (F.tiles + 3) / 4));
+    if (const char* e = getenv("ZNS_XQT_TPW")) F.tpw = std::max(1, std::min(FB_TPW, atoi(e)));   // tuning aid
+    F.blocks_per_clip = (F.tiles + 4 * F.tpw - 1) / (4 * F.tpw);
+    F.n_clips = n_clips;
+    {
+        int ord[XQ_OCT];
+        for (int i = 0; i < XQ_OCT; ++i) ord[i] = i;
+        std::stable_sort(ord, ord + XQ_OCT, [&](int x, int y) { return b->n_fft[x] > b->n_fft[y]; });
+        for (int i = 0; i < XQ_OCT; ++i) F.order[i] = (unsigned char)ord[i];
+    }
     F.out = out;
     int wf = 0;   // floats of one wave's staging region: the largest segment image over the octaves
     for (int i = 0; i < XQ_OCT; ++i) {
@@ -701,14 +663,14 @@ int zns_xqt_stages_f32(const float* wav, int n_clips, int n_samples, int sample_
     for (int i = 0; i < XQ_OCT; ++i) max_fft = std::max(max_fft, b->n_fft[i]);
     static bool lds_set[2][ZNS_MAX_DEVICES] = {};
     const int big = max_fft > 128 ? 1 : 0;
+    using Kern = void (*)(FbArgs);
+    static const Kern kerns[2] = {xqt_filter_kernel<128>, xqt_filter_kernel<256>};
     if (!lds_set[big][current_device_slot()]) {
-        ZNS_HIP(hipFuncSetAttribute(big ? (const void*)xqt_filter_kernel<256> : (const void*)xqt_filter_kernel<128>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ZNS_HIP(hipFuncSetAttribute((const void*)kerns[big], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         lds_set[big][current_device_slot()] = true;
     }
-    const dim3 grid((unsigned)((size_t)n_clips * F.blocks_per_clip));
-    if (big) hipLaunchKernelGGL(xqt_filter_kernel<256>, grid, dim3(256), lds, st, F);
-    else hipLaunchKernelGGL(xqt_filter_kernel<128>, grid, dim3(256), lds, st, F);
+    const dim3 grid((unsigned)((size_t)XQ_OCT * n_clips * F.blocks_per_clip));
+    hipLaunchKernelGGL(kerns[big], grid, dim3(256), lds, st, F);
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
 }
