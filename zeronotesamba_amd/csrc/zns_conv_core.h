@@ -500,6 +500,7 @@ struct WgCfg {
     static constexpr int NXI = (XBUF / 64 + NW - 1) / NW;    // X-patch DMA instructions per wave
     static constexpr int NZI = (COB / RPI + NW - 1) / NW;    // dZ-tile DMA instructions per wave (16-byte pieces)
     static constexpr int LDS_BYTES = 2 * (ZBUF + XBUF) * 4;
+    static constexpr int WPE = (NW == 4 && 2 * LDS_BYTES <= 160 * 1024) ? 2 : 1;   // 4-wave workgroups: two per CU
     static_assert(R == 1, "one image row per K-tile");
     static_assert(CW == 32 || CW == 64, "K-tile width");
     static_assert(CIN % CIB == 0 && COUT % COB == 0, "tiling");
@@ -578,7 +579,7 @@ __device__ __forceinline__ void wg_load_tile(const WgArgs& A, int br, int cob, i
 }
 
 template <class C>
-__global__ void __launch_bounds__(C::NT) wgrad_core(WgArgs A) {
+__global__ void __launch_bounds__(C::NT, C::WPE) wgrad_core(WgArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     auto zbuf = [&](int i) -> float* { return smem + (i & 1) * C::ZBUF; };
     auto xbuf = [&](int i) -> float* { return smem + 2 * C::ZBUF + (i & 1) * C::XBUF; };
@@ -753,7 +754,7 @@ static int wg_pick_ks(const ConvArgs& a, int* tiles_total, int* tps) {
     const int ncb = ceil_div(a.T, C::CW);
     const int total = a.B * C::H * ncb;
     const int base = C::NQG * (C::CIN / C::CIB) * (C::COUT / C::COB) * a.nbr;
-    const int cus = device_cus();
+    const int cus = device_cus() * C::WPE;    // resident workgroup slots
     int best_ks = 1;
     double best_eff = -1.0;
     const int ks_max = total < 256 ? total : 256;
