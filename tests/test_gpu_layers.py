@@ -54,6 +54,20 @@ def test_conv_layer_at_bench_shapes(li, T):
     check_conv_layer(li, "auto", T, nbr=2, B=1)
 
 
+# Ragged and extreme widths: the shortest rows the frequency path takes (T = 32; below that the dispatcher falls back to
+# the direct kernels), widths that are not a multiple of 4 (no 16-byte row alignment anywhere), a one-window row, a lone
+# branch with an odd batch, and a 60 s clip (T = 3751: NS = 7..8 row segments per sample).
+RAGGED = [(1, 31, 2, 1), (1, 32, 1, 3), (2, 33, 2, 1), (3, 45, 1, 1), (4, 97, 2, 1), (5, 35, 1, 2), (6, 50, 2, 1),
+          (3, 3751, 1, 1), (1, 2501, 1, 1)]
+
+
+@pytest.mark.parametrize("li,T,nbr,B", RAGGED)
+def test_conv_layer_ragged_and_long(li, T, nbr, B):
+    from conftest import host_threads
+    torch.set_num_threads(host_threads())
+    check_conv_layer(li, "auto", T, nbr=nbr, B=B)
+
+
 def check_conv_layer(li, impl, T, nbr, B):
     _lib, _ops = _mods()
     L = _lib.lib()
