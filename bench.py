@@ -443,8 +443,8 @@ def main():
             res["config"]["finetune"] = measure_finetune(dev, cpu)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
-            res["cpu_baseline"]["sample"] += ("; GPU-utilisation samplers see ~0 % on this command: the timed GPU region is "
-                                              "under a second inside tens of seconds of CPU baseline")
+            res["cpu_baseline"]["sample"] += ("; GPU-utilisation samplers see little on this command: the timed GPU region is "
+                                              "about a second inside tens of seconds of CPU baseline")
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
