@@ -469,8 +469,8 @@ __global__ void __launch_bounds__(256) spec_dc_sum_kernel(const float* __restric
 using FF2 = ConvCfg<64, 64, 1, 7, 1, 2, 1, 2, 1, 1, 4, 8, 1, 1, FDIL>;
 using FF3 = ConvCfg<64, 128, 1, 5, 1, 4, 1, 1, 1, 1, 12, 8, 1, 1, FDIL, 8>;
 using FF4 = ConvCfg<128, 128, 1, 9, 1, 4, 1, 1, 1, 1, 12, 8, 1, 1, FDIL, 8>;
-using FF5 = ConvCfg<128, 256, 1, 3, 1, 2, 1, 1, 4, 1, 3, 16, 1, 1, FDIL>;
-using FF6 = ConvCfg<256, 256, 1, 5, 1, 2, 1, 1, 4, 1, 3, 8, 1, 1, FDIL>;
+using FF5 = ConvCfg<128, 256, 1, 3, 1, 2, 1, 1, 4, 1, 3, 8, 1, 1, FDIL>;
+using FF6 = ConvCfg<256, 256, 1, 5, 1, 2, 1, 1, 4, 1, 3, 4, 1, 1, FDIL>;
 // narrower variants for short flattened axes (e.g. T = 313 / 626: P = 224 for cv3/cv4, 56..64 for cv5/cv6)
 using FF3a = ConvCfg<64, 128, 1, 5, 1, 4, 1, 1, 1, 1, 8, 8, 1, 1, FDIL, 4>;    // 7 column tiles, 8 waves
 using FF4a = ConvCfg<128, 128, 1, 9, 1, 4, 1, 1, 1, 1, 8, 8, 1, 1, FDIL, 4>;
