@@ -470,7 +470,11 @@ __device__ __forceinline__ void fb_run(const FbArgs& P, const FbRun r, int clip,
                 const int k = (q & 1) + 4 * (q >> 1) + 2 * kk;                       // row = (reg & 3) + 8 (reg >> 2) + 4 kk, reg = 2q
                 const float re = acc[2 * q], im = acc[2 * q + 1];
                 const int kbin = XQ_BINS - XQ_BPO * (oct + 1) + k;
-                P.out[((size_t)clip * XQ_BINS + kbin) * P.n_frames + t] = logf(sqrtf(re * re + im * im) + 1e-9f);
+                // hardware sqrt / log2 (1 ulp each): 2e-6 absolute in the log domain at most, a fiftieth of the parity
+                // tolerance, and a fifth of the instructions of the correctly rounded library forms -- the epilogue is
+                // per-tile work that the 8- and 16-MFMA octaves cannot hide
+                P.out[((size_t)clip * XQ_BINS + kbin) * P.n_frames + t] =
+                    __logf(__builtin_amdgcn_sqrtf(re * re + im * im) + 1e-9f);
             }
         }
     }
