@@ -489,7 +489,7 @@ using FD6 = FF6;
 using FW2 = WgCfg<64, 64, 1, 7, 1, 1, 7, 2, 1, 1, FDILW, 2, 32>;
 using FW3 = WgCfg<64, 128, 1, 5, 1, 1, 5, 4, 1, 1, FDILW, 2, 32>;
 using FW4 = WgCfg<128, 128, 1, 9, 1, 2, 3, 2, 3, 1, FDILW, 2, 32>;
-using FW5 = WgCfg<128, 256, 1, 3, 1, 2, 3, 2, 1, 1, FDILW, 4, 32>;
+using FW5 = WgCfg<128, 256, 1, 3, 1, 2, 3, 2, 1, 1, FDILW, 2, 32>;
 using FW6 = WgCfg<256, 256, 1, 5, 1, 2, 5, 4, 1, 1, FDILW, 2, 32>;
 
 struct FftGeom {
