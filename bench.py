@@ -2,7 +2,7 @@
 """Pretext-step benchmark (BASELINE.json config 3 / 5): batch=16 pairs of synthetic 1x96x512 VQT tensors per GPU,
 twin-branch Pretext_CNN forward + NT-Xent + backward + Adam, dropout active, fp32.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1: starts its own N rank processes, see self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0.  `value` = pretext steps/sec summed over ranks (each rank steps on its own
@@ -215,7 +215,9 @@ def measure_module_path(dev, iters: int = 10) -> dict:
             a, p = model(anchors, postves)
             crit(a, p)
 
-    out["val_batch_ms"] = _timed(val_step, iters, 3)
+    import zeronotesamba_amd
+    with zeronotesamba_amd.frozen_weights():      # as val_epoch holds it around its loop: weight operands packed once
+        out["val_batch_ms"] = _timed(val_step, iters, 3)
     return out
 
 
@@ -310,6 +312,75 @@ def measure_finetune(dev, cpu: bool, iters: int = 10) -> dict:
     return out
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` without torchrun's environment: start N FRESH rank processes (this file, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would) and relay rank 0's JSON line.
+    The parent makes no HIP call before or after (counting devices does not initialise the GPU on this image), never
+    exec()s, and kills by exact PID only.  Returns the exit code: non-zero if any rank failed."""
+    import socket
+    import subprocess
+    backend = os.environ.get("ZNS_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < n:
+        print(f"bench.py: --gpus {n} but this node exposes {have} GPU(s); RCCL needs one device per rank "
+              "(ZNS_BENCH_BACKEND=gloo runs a functional dry run with ranks sharing devices)", file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL's intra-node transport on this pool
+        env.setdefault("OMP_NUM_THREADS", "1")                # as torch.distributed.run sets it
+        # rank 0's stdout carries the one JSON line; the other ranks' stdout is diagnostics only
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
+    import threading
+    rc = 0
+    found = []
+
+    def relay():                                               # ends when rank 0 closes its stdout (exit)
+        for raw in procs[0].stdout:
+            if raw.startswith("{") and not found:
+                found.append(raw.rstrip("\n"))
+            else:
+                sys.stderr.write(raw)
+
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+    try:
+        deadline = time.time() + float(os.environ.get("ZNS_BENCH_LAUNCH_TIMEOUT", "3600"))
+        pending = list(procs)
+        while pending and time.time() < deadline:
+            for p in list(pending):
+                c = p.poll()
+                if c is not None:
+                    pending.remove(p)
+                    rc = rc or c
+            if rc:                                             # one rank died: its peers would wait in a collective
+                break
+            time.sleep(0.05)
+        if pending:
+            rc = rc or 1
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    th.join(timeout=10)
+    line = found[0] if found else None
+    if rc == 0 and line is None:
+        rc = 1
+    if rc == 0:
+        print(line, flush=True)
+    else:
+        print(f"bench.py: a rank exited with code {rc}; no result line", file=sys.stderr)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -318,6 +389,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the module-path / generate_XQT / fine-tune measurements")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     from zeronotesamba_amd import _lib
     from zeronotesamba_amd.distributed import init_from_env

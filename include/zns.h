@@ -47,10 +47,13 @@ extern "C" {
 
 const char* zns_last_error(void);
 int zns_version(void);
-/* Select the kernel family for conv fwd/dgrad/wgrad (process global).  Returns the previous value. */
+/* TEST / BENCH ONLY.  Select the kernel family for the CALLING THREAD's conv fwd/dgrad/wgrad calls (thread-local, so a
+ * validation run on the naive kernels cannot redirect another thread's launches).  Returns the previous value. */
 int zns_set_impl(int impl);
 
-/* Measurement hook for bench.py: record hipEvents immediately around the MAIN kernel of the next
+/* TEST / BENCH ONLY.  One probe per process, owned by the arming thread: only that thread's launches are recorded;
+ * arming while a probe is armed, or disarming from another thread, returns ZNS_ERR_ARG.
+ * Measurement hook for bench.py: record hipEvents immediately around the MAIN kernel of the next
  * conv launches that match (kind, cin, cout, kh).  kind: 0 forward, 1 backward-data, 2 backward-weights.
  * ev_start/ev_stop: host arrays of n hipEvent_t (created with timing enabled); launch i uses slot
  * i % n.  n == 0 disarms.  Returns the number of matching launches recorded so far via zns_probe_count(). */
@@ -138,7 +141,7 @@ int zns_down_bwd_f32(const float* a, const float* p, const float* dout, size_t n
                      float* da, float* dp, void* stream);
 
 /* ------------------------------------------------------------------ NT-Xent (loss_functions.py:24-55)
- * a, p: [rows, D] (rows <= batch_len; any batch size, as config.yaml's batch_size).  out3 (device, 3 floats): loss,
+ * a, p: [rows, D] (rows <= batch_len, 1 <= rows <= 2048: config.yaml's batch_size is 16).  out3 (device, 3 floats): loss,
  * mean anchor/positive cosine, mean anchor/negative cosine -- all divided by batch_len as the reference does.
  * ga/gp (nullable): d(loss*grad_scale)/da, /dp.  ws: zns_ntxent_workspace_bytes(rows) bytes of device scratch. */
 size_t zns_ntxent_workspace_bytes(int rows);

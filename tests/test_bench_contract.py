@@ -85,3 +85,36 @@ def test_bench_two_ranks_dry_run_on_one_gpu():
     assert r["config"]["ms_per_step_without_allreduce"] > 0 and r["config"]["allreduce_buckets"] >= 3
     assert "cpu_baseline" not in r
     assert abs(r["value"] - 2 * 1000.0 / r["ms_per_step"]) < 1e-6 * r["value"]      # whole-job steps/s
+
+
+@pytest.mark.gpu
+def test_bench_self_launches_its_ranks_without_torchrun():
+    """`python bench.py --gpus 2` with NO torchrun environment (how a driver may call it): bench.py starts the two rank
+    processes itself before touching the GPU and relays rank 0's one JSON line.  gloo backend: both ranks share this
+    box's one GPU -- a functional run, not a performance number."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["ZNS_BENCH_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and out.stdout.strip() == lines[0], out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["warmup"] == 1 and r["config"]["parallelism"] == "dp2"
+    assert abs(r["value"] - 2 * 1000.0 / r["ms_per_step"]) < 1e-6 * r["value"]
+    # and a launch that cannot work says so with a non-zero exit instead of hanging or printing a number
+    env.pop("ZNS_BENCH_BACKEND")
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_refuses_more_ranks_than_gpus_without_a_result_line():
+    """CPU side of the same contract: no GPU here, so `--gpus 2` must exit non-zero, quickly, with no JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "ZNS_BENCH_BACKEND")}
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has the GPUs")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and "{" not in out.stdout

@@ -228,3 +228,79 @@ def test_full_size_step_against_the_cpu_oracle():
     for name, p in model.named_parameters():
         assert rel_l2(p.grad, ref2[name]) < 3e-2, name
     assert rel_l2(model.anchor.fc1.weight.grad, ref2["anchor.fc1.weight"]) < 2e-4
+
+
+@pytest.mark.parametrize("red", ["max", "mean"])
+def test_finetune_step_full_size_against_the_cpu_oracle(red):
+    """BASELINE config 4 at its full size (epochs.py:48-63 through loader.load_models("pretrained", "finetune"),
+    loader.py:43): Down_CNN(max / mean), batch of ONE 30 s clip (T = 1876: every spectral layer runs NS > 1 row
+    segments), the 120-BPM {0, 0.5, 1} mask bench.py uses, BCELoss, Adam(lr = 0.5 * 1e-5 * 10e-2).  Whole step against
+    the CPU oracle (one oracle step is ~3 s on the box's host cores) with the device's max-pool / ReLU decisions
+    replayed: loss 2e-5, output 1e-4, every parameter gradient <= 1e-4 of its L2 norm, post-Adam parameters 1e-5 --
+    and, because an update of lr = 5e-7 hides inside that 1e-5, the UPDATE itself: Adam's first step moves a parameter
+    by lr * g / (|g| + eps), so device and oracle may only differ where a gradient element is within their 1e-4
+    disagreement of zero."""
+    import contextlib
+    import io
+    from conftest import host_threads
+    from oracle import cnn_ref, step_ref
+    from replay_util import device_decisions, flip_summary, grad_err, total_flips
+    from zeronotesamba_amd import _ops
+    from zeronotesamba_amd.loader import load_models
+    T, lr = 1876, 0.5 * 1e-5 * 10e-2
+    torch.set_num_threads(host_threads())
+    sd = cnn_ref.synth_state_dict(7, 2.0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        crit, opt, d = load_models("pretrained", "finetune", 1e-5, state_dict=sd, device=DEV)
+    d.reduction = red
+    d.eval()                                            # dropout off: the oracle's masks are then the ReLU decisions only
+    assert abs(opt.param_groups[0]["lr"] - lr) < 1e-18
+    vqt = cnn_ref.synth_vqt(300 + T, (2, 96, T))
+    msk = torch.zeros(T)
+    msk[5::31] = 1.0
+    msk[4::31] = 0.5
+    msk[6::31] = 0.5
+    v1, v2 = vqt[0].reshape(1, 1, 96, T).to(DEV), vqt[1].reshape(1, 1, 96, T).to(DEV)
+    before = {k: v.detach().cpu().clone() for k, v in d.named_parameters()}
+    opt.zero_grad()
+    o = d(v1, v2)
+    loss = crit(o, msk.reshape(1, T).to(DEV))
+    loss.backward()
+    grads = {k: v.grad.detach().cpu().clone() for k, v in d.named_parameters()}
+    opt.step()
+    torch.cuda.synchronize()
+    P = _ops.StackParams.from_flat(d.pretext.anchor.stack_params() + d.pretext.postve.stack_params(), 2)
+    # the decisions the step took: same kernels on the pre-update weights are bitwise repeatable, so re-run on a copy
+    d0 = type(d)(reduction=red)
+    d0.pretext.load_state_dict(sd)
+    d0.to(DEV).eval()
+    P0 = _ops.StackParams.from_flat(d0.pretext.anchor.stack_params() + d0.pretext.postve.stack_params(), 2)
+    replay, emb0 = device_decisions(torch.cat([v1, v2]), P0, 1)
+    op = step_ref.OracleParams({"pretext." + k: v for k, v in sd.items()}, lr)
+    flips = {}
+    rl, ro = step_ref.finetune_step(op, vqt, msk, reduction=red, step_opt=True, replay=replay, flips=flips)
+    print(f"fine-tune step T={T} ({red}) vs CPU oracle, decisions replayed: loss {loss.item():.6f}/{rl:.6f};",
+          flip_summary(flips), "(total %d)" % total_flips(flips))
+    assert abs(loss.item() - rl) < 2e-5
+    assert (o.detach().cpu() - ro).abs().max().item() < 1e-4
+    ref = op.grads()
+    worst = 0.0
+    for k in grads:
+        e = grad_err(k, grads[k], ref)
+        worst = max(worst, e)
+        assert e <= 1e-4, (k, e)
+    print("  worst per-parameter gradient rel L2: %.2e" % worst)
+    after_ref = op.values()
+    n_all = n_bad = 0
+    for k, v in d.named_parameters():
+        got, want = v.detach().cpu(), after_ref[k]
+        assert (got - want).abs().max().item() <= 1e-5 * max(want.abs().max().item(), 1e-3), k
+        # the update: both sides moved by lr * g / (|g| + eps); elements whose gradient is within the 1e-4 disagreement
+        # of zero may take the other sign (2 * lr apart), everything else must agree to a tenth of lr
+        dd, dr = (got - before[k]).double(), (want - before[k]).double()
+        bad = ((dd - dr).abs() > 0.1 * lr)
+        n_all += bad.numel()
+        n_bad += int(bad.sum())
+        assert 0.5 * lr < float(dd.abs().max()) <= 1.1 * lr, k          # fp32 rounding of p - step: one ulp of p
+    print("  Adam update: %d of %d elements differ by more than lr/10" % (n_bad, n_all))
+    assert n_bad <= 1e-3 * n_all

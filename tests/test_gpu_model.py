@@ -280,12 +280,14 @@ def test_finetune_step_gradients_with_replayed_decisions(red):
             assert grad_err(k, v.grad, ref) <= 1e-4, (T, k, grad_err(k, v.grad, ref))
 
 
-def test_packed_weights_are_cached_until_the_weights_change(monkeypatch):
-    """The kernel-order weight operand (frequency weights: 0.5 GB per forward over cv2..cv6 at B=16) is built once per
-    weight VERSION: repeated eval-mode calls (val_epoch pretext.py:527-592, sample_script.py:46-48) launch no pack
-    kernel after the first, any optimizer step (stock torch Adam, the fused Adam, the fused trainer) invalidates it, and
-    a stale operand is never used: outputs always equal those of a freshly built model holding the same weights."""
-    from zeronotesamba_amd import _lib
+def test_packed_weights_are_cached_only_inside_a_frozen_weights_scope(monkeypatch):
+    """The kernel-order weight operand (frequency weights: 0.5 GB per forward over cv2..cv6 at B=16) is cached ONLY inside
+    an explicit `frozen_weights()` scope (val_epoch pretext.py:527-592 and the fused evaluate_epoch hold one; an inference
+    loop like sample_script.py:46-48 opts in).  Outside it nothing is cached, so a write the version counters cannot see
+    (`p.data.mul_()`) is always honoured; inside it an optimizer step still invalidates; leaving it drops the operands.
+    A stale operand is never used: outputs always equal those of a freshly built model holding the same weights."""
+    import zeronotesamba_amd
+    from zeronotesamba_amd import _lib, _ops
     from zeronotesamba_amd.models.loss_functions import NTXent
     from zeronotesamba_amd.models.models import Pretext_CNN
     from zeronotesamba_amd.optim import Adam
@@ -300,62 +302,83 @@ def test_packed_weights_are_cached_until_the_weights_change(monkeypatch):
         m.load_state_dict(sd)
         return m.to(DEV).eval()
 
+    def cached(m):
+        return [p for p in m.parameters() if p.__dict__.get("_zns_pack")]
+
     B, T = 2, 72
     sd = cnn_ref.synth_state_dict(3, 2.0)
     m = fresh(sd)
     anc, pos = cnn_ref.synth_vqt(101, (B, 1, 96, T)).to(DEV), cnn_ref.synth_vqt(102, (B, 1, 96, T)).to(DEV)
+    # ---- outside a scope: every call packs into its own workspace (no pack ENTRY-POINT call, nothing kept) ...
     with torch.no_grad():
         a1, p1 = m(anc, pos)
+        assert not calls and not cached(m)
+        # ... so the write autograd's version counters cannot see is honoured
+        m.anchor.pretrained.cv4.weight.data.mul_(1.5)
+        a2, p2 = m(anc, pos)
+        ar, pr = fresh({k: v.detach().cpu() for k, v in m.state_dict().items()})(anc, pos)
+    assert torch.equal(a2, ar) and torch.equal(p2, pr) and not torch.equal(a2, a1)
+    # ---- inside a scope: one pack per operand, then none
+    with torch.no_grad(), zeronotesamba_amd.frozen_weights():
+        a3, p3 = m(anc, pos)
         n1 = len(calls)
         assert n1 == 7 and not any(calls)                       # cv2..cv8 forward operands, cv1 takes the weights as they are
-        a2, p2 = m(anc, pos)
-        a3 = m.anchor(cnn_ref.synth_vqt(103, (1, 1, 96, 40)).to(DEV))      # another T, lone branch: nbr = 1 operand
+        a4, p4 = m(anc, pos)
+        assert len(calls) == n1
+        m.anchor(cnn_ref.synth_vqt(103, (1, 1, 96, 40)).to(DEV))           # another T, lone branch: nbr = 1 operand
         assert len(calls) == n1 + 7
         m.anchor(cnn_ref.synth_vqt(104, (3, 1, 96, 40)).to(DEV))           # another batch size, same layout: no new pack
         assert len(calls) == n1 + 7
-    assert torch.equal(a1, a2) and torch.equal(p1, p2)
+        assert cached(m)
+        with zeronotesamba_amd.frozen_weights():                             # re-entrant: the inner exit drops nothing
+            pass
+        assert cached(m)
+    assert not cached(m)                                                     # leaving the outermost scope drops them
+    assert torch.equal(a3, a2) and torch.equal(a4, a2) and torch.equal(p4, p2)
+    # ---- val_epoch holds the scope around its own loop: seven packs for a whole epoch
     crit = NTXent(B, 0.25)
     loader = [[cnn_ref.synth_vqt(200 + i, (B, 2, 96, T))] for i in range(3)]
     n = len(calls)
     val_epoch(m, loader, crit, None)
-    assert len(calls) == n                                      # a whole validation epoch without a single pack launch
-    # with gradients ON the cache is never trusted (a write through `.data` does not bump the version counter): every call
-    # repacks; a training step changes the weights and the next no-grad forward follows them
+    assert len(calls) == n + 7 and not cached(m)
+    # ---- an optimizer step INSIDE a scope bumps the version counters: the next forward repacks and follows the weights
     for make_opt in (lambda ps: torch.optim.Adam(ps, lr=1e-5), lambda ps: Adam(ps, lr=1e-5)):
         opt = make_opt(m.parameters())
-        n = len(calls)
-        a, p = m(anc, pos)
-        assert len(calls) == n + 7
-        loss, _, _ = crit(a, p)
-        loss.backward()
-        assert len(calls) == n + 14 and sum(calls[n + 7:]) == 7       # the seven backward-data operands
-        opt.step()
-        n = len(calls)
-        with torch.no_grad():
-            a4, p4 = m(anc, pos)
+        with zeronotesamba_amd.frozen_weights():
+            n = len(calls)
+            a, p = m(anc, pos)
             assert len(calls) == n + 7
-            ar, pr = fresh({k: v.detach().cpu() for k, v in m.state_dict().items()})(anc, pos)
-        assert torch.equal(a4, ar) and torch.equal(p4, pr) and not torch.equal(a4, a1)
-    # the documented blind spot and its remedy: a `.data` write between two no-grad forwards needs invalidate_packed
-    from zeronotesamba_amd import _ops
-    with torch.no_grad():
-        m.anchor.pretrained.cv4.weight.data.mul_(1.5)
-        _ops.invalidate_packed(m)
-        a6, p6 = m(anc, pos)
-        ar, pr = fresh({k: v.detach().cpu() for k, v in m.state_dict().items()})(anc, pos)
-    assert torch.equal(a6, ar) and torch.equal(p6, pr)
+            loss, _, _ = crit(a, p)
+            loss.backward()
+            assert len(calls) == n + 14 and sum(calls[n + 7:]) == 7       # the seven backward-data operands
+            opt.step()
+            n = len(calls)
+            with torch.no_grad():
+                a5, p5 = m(anc, pos)
+                assert len(calls) == n + 7
+                ar, pr = fresh({k: v.detach().cpu() for k, v in m.state_dict().items()})(anc, pos)
+            assert torch.equal(a5, ar) and torch.equal(p5, pr) and not torch.equal(a5, a2)
+            # the blind spot, now only reachable by breaking the scope's promise -- and its remedy
+            with torch.no_grad():
+                m.anchor.pretrained.cv4.weight.data.mul_(1.5)
+                _ops.invalidate_packed(m)
+                a6, p6 = m(anc, pos)
+                ar, pr = fresh({k: v.detach().cpu() for k, v in m.state_dict().items()})(anc, pos)
+            assert torch.equal(a6, ar) and torch.equal(p6, pr)
+    # ---- the fused trainer: evaluate_epoch packs once per epoch, a step in between invalidates
     tr = PretextTrainer(m, batch_len=B, lr=1e-5, train=False)
-    x = tr.stack_inputs(loader[0][0])
-    e0 = tr.evaluate(x)
+    xs = [tr.stack_inputs(l[0]) for l in loader]
     n = len(calls)
-    assert torch.equal(tr.evaluate(x), e0) and len(calls) == n
-    tr.step(x)
-    e1 = tr.evaluate(x)
-    assert not torch.equal(e1, e0)
+    e0 = tr.evaluate_epoch(xs)
+    assert len(calls) == n + 7
+    assert tr.evaluate_epoch(xs) == e0
+    tr.step(xs[0])
+    e1 = tr.evaluate_epoch(xs)
+    assert e1 != e0
     with torch.no_grad():
-        ar, pr = fresh({k: v.detach().cpu() for k, v in m.state_dict().items()})(x[:B], x[B:])
-        a5, p5 = m(x[:B], x[B:])
-    assert torch.equal(a5, ar) and torch.equal(p5, pr)
+        ar, pr = fresh({k: v.detach().cpu() for k, v in m.state_dict().items()})(xs[0][:B], xs[0][B:])
+        a7, p7 = m(xs[0][:B], xs[0][B:])
+    assert torch.equal(a7, ar) and torch.equal(p7, pr)
 
 
 def test_frozen_backbone_gets_no_conv_grads():
@@ -410,3 +433,47 @@ def test_config1_sample_script_plumbing():
         want = cnn_ref.down_forward({"pretext." + k: v for k, v in sd.items()}, ra, rp)
     err = (combined.cpu() - want).abs().max().item()
     assert err < 1e-4, err
+
+
+def test_two_streams_on_one_device_do_not_share_scratch():
+    """Scratch (split-K slabs, spectra, packed weights) is keyed by (device, stream, slot): two forwards in flight on two
+    streams of one device must give the embeddings a lone stream gives."""
+    from zeronotesamba_amd import _ops
+    from zeronotesamba_amd.models.models import Pretext_CNN
+    m = Pretext_CNN()
+    m.load_state_dict(cnn_ref.synth_state_dict(3, 2.0))
+    m.to(DEV).eval()
+    B, T = 4, 200
+    xs = [(cnn_ref.synth_vqt(400 + i, (B, 1, 96, T)).to(DEV), cnn_ref.synth_vqt(450 + i, (B, 1, 96, T)).to(DEV)) for i in range(2)]
+    with torch.no_grad():
+        want = [m(a, p) for a, p in xs]
+    torch.cuda.synchronize()
+    n_ws = len(_ops._workspaces)
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(2)]
+    got = [None, None]
+    with torch.no_grad():
+        for rep in range(3):                              # interleave launches of the two streams
+            for i, s in enumerate(streams):
+                with torch.cuda.stream(s):
+                    got[i] = m(*xs[i])
+    torch.cuda.synchronize()
+    assert len(_ops._workspaces) >= n_ws + 2              # each side stream got its own scratch
+    for (wa, wp), (ga, gp) in zip(want, got):
+        assert torch.equal(wa, ga) and torch.equal(wp, gp)
+
+
+def test_probe_is_single_owner():
+    """zns_probe_arm (bench-only hook): a second arm while one is armed is refused instead of silently replacing it."""
+    from zeronotesamba_amd import _lib
+    L = _lib.lib()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for e in ev:
+        e.record()
+    torch.cuda.synchronize()
+    a0, a1 = _lib.ptr_array([ev[0].cuda_event]), _lib.ptr_array([ev[1].cuda_event])
+    assert L.zns_probe_arm(0, 128, 128, 9, a0, a1, 1) == 0
+    try:
+        assert L.zns_probe_arm(0, 64, 64, 7, a0, a1, 1) != 0
+        assert b"already armed" in L.zns_last_error()
+    finally:
+        assert L.zns_probe_arm(0, 0, 0, 0, None, None, 0) == 0

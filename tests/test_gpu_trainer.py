@@ -339,3 +339,108 @@ def test_rccl_bucketed_allreduce_on_the_launch_streams():
         assert torch.equal(oa, ob) and torch.equal(ta.flat_g, tb.flat_g) and torch.equal(ta.flat_p, tb.flat_p)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_two_rank_trainer_replicas_stay_identical_and_equal_the_accumulated_step(tmp_path, train):
+    """SURVEY 8e on the REAL trainer: two rank processes (fresh interpreters, tests/dp_worker.py) that start from
+    DIFFERENT weights and step three times on DIFFERENT batches must (a) hold bit-identical parameters and Adam moments
+    afterwards (construction-time broadcast + every step's all-reduce), and (b) equal a one-process run that starts
+    from rank 0's weights, accumulates the two ranks' batch gradients and applies the fused Adam with grad_scale = 1/2
+    -- the semantics pretext.py:475-492 has per rank with the mean gradient (global batch = 2 x 16 shifts, local
+    NT-Xent per clip).  train=True: dropout on, each rank draws its own masks (the seed folds the rank in)."""
+    import socket
+    import subprocess
+    import sys
+    import os
+    import dp_worker as W
+    from zeronotesamba_amd.models.models import Pretext_CNN
+    from zeronotesamba_amd.pretext import PretextTrainer
+    steps = 3
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(tmp_path), str(int(train)), str(steps)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    r0, r1 = (torch.load(tmp_path / f"rank{r}.pt") for r in range(2))
+    assert r0["world"] == r1["world"] == 2 and r0["step_count"] == r1["step_count"] == steps and r0["buckets"] >= 3
+    # replicas start from rank 0's weights whatever they were built with ...
+    m = Pretext_CNN()
+    m.load_state_dict(W.rank_state_dict(0))
+    tr = PretextTrainer(m.to(DEV), batch_len=W.B, temperature=W.TAU, lr=W.LR, seed=W.SEED, train=train)
+    assert torch.equal(r0["p0"], tr.flat_p.cpu()) and torch.equal(r1["p0"], r0["p0"])
+    # ... (a) and end bit-identical
+    for k in ("p", "m", "v"):
+        assert torch.equal(r0[k], r1[k]), k
+    assert not torch.equal(r0["out"], r1["out"])                  # they did see different batches
+    # (b) one process, the two batches accumulated, Adam on half the sum
+    for st in range(steps):
+        tr.rank = 0
+        o0 = tr.step(tr.stack_inputs(W.rank_batch(st, 0)), update=False)
+        g0 = tr.flat_g.clone()
+        tr.rank = 1
+        o1 = tr.step(tr.stack_inputs(W.rank_batch(st, 1)), update=False)
+        tr.flat_g += g0
+        tr.rank = 0
+        tr.apply_update(0.5)
+        assert torch.equal(o0.cpu(), r0["out"][st]) and torch.equal(o1.cpu(), r1["out"][st]), st
+    for k, mine in (("p", tr.flat_p), ("m", tr.flat_m), ("v", tr.flat_v)):
+        d = (mine.cpu() - r0[k]).abs().max().item()
+        print(f"two ranks vs one accumulated process, flat_{k}: max |diff| {d:.3e}, bitwise {torch.equal(mine.cpu(), r0[k])}")
+        assert d <= 1e-6, (k, d)
+    assert (tr.flat_p.cpu() - r0["p0"]).abs().max().item() > 0.5 * W.LR      # and the weights did move
+
+
+def test_checkpoint_round_trip_through_the_fused_trainer(tmp_path):
+    """pretext.py:409-412 / loader.py:25-27 / sample_script.py:42: `torch.save(model.state_dict())` of a model whose
+    parameters are views into the trainer's flat buffer, loaded into a fresh Pretext_CNN, into a model that already
+    HAS a trainer, and into Down_CNN().pretext."""
+    import os
+    from zeronotesamba_amd.models.models import Down_CNN, Pretext_CNN
+    from zeronotesamba_amd.pretext import PretextTrainer
+    B, T = 2, 72
+    m = make_model(5)
+    tr = PretextTrainer(m, batch_len=B, lr=1e-3, train=False)
+    x = tr.stack_inputs(cnn_ref.synth_vqt(210, (B, 2, 96, T)))
+    tr.step(x)
+    tr.step(x)
+    path = tmp_path / "shift_pret_cnn_16.pth"
+    torch.save(m.state_dict(), path)                                           # pretext.py:410
+    n_par = sum(p.numel() for p in m.parameters())
+    size = os.path.getsize(path)
+    assert n_par == 26819202 and n_par * 4 <= size < n_par * 4 * 1.01, size    # 107 MB, not 36 copies of the flat buffer
+    e_tr = tr.evaluate(x)
+    with torch.no_grad():
+        a0, p0 = m.eval()(x[:B], x[B:])
+    # (a) fresh model
+    f = Pretext_CNN()
+    f.load_state_dict(torch.load(path, map_location="cpu"))
+    f.to(DEV).eval()
+    with torch.no_grad():
+        a1, p1 = f(x[:B], x[B:])
+    assert torch.equal(a0, a1) and torch.equal(p0, p1)
+    # (b) a model that already has a trainer: the views stay views of the flat buffer, cached packed operands follow
+    m2 = make_model(9)
+    tr2 = PretextTrainer(m2, batch_len=B, lr=1e-3, train=False)
+    from zeronotesamba_amd import _ops
+    with _ops.frozen_weights():                    # operands cached across the two evaluations: the load must invalidate them
+        e_before = tr2.evaluate(x)
+        m2.load_state_dict(torch.load(path, map_location=DEV))
+        tr2._check_flat()
+        lo, hi = tr2.flat_p.data_ptr(), tr2.flat_p.data_ptr() + tr2.n_flat * 4
+        assert all(lo <= p.data_ptr() < hi for p in m2.parameters())
+        e_after = tr2.evaluate(x)
+    assert not torch.equal(e_before, e_after) and torch.equal(e_after, e_tr)
+    o_a, o_b = tr.step(x), tr2.step(x)                                         # and training continues from there
+    assert torch.equal(o_a, o_b)
+    # (c) Down_CNN().pretext.load_state_dict (loader.py:27, sample_script.py:42)
+    d = Down_CNN()
+    d.pretext.load_state_dict(torch.load(path, map_location="cpu"))
+    d.to(DEV).eval()
+    with torch.no_grad():
+        comb = d(x[:B], x[B:])
+    assert torch.equal(comb, torch.maximum(a0, p0))

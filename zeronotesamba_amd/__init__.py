@@ -12,3 +12,10 @@ All arithmetic runs in hand-written HIP kernels behind the C ABI of include/zns.
 (libzns_hip.so, loaded with ctypes).  There is no CPU or stock-PyTorch fallback.
 """
 __version__ = "0.1.0"
+
+
+def frozen_weights():
+    """Context manager for inference / validation loops that call the model many times with unchanged weights
+    (sample_script.py:46-48 over many files): the kernel-order weight operands are then built once, see _ops.frozen_weights."""
+    from ._ops import frozen_weights as _fw
+    return _fw()

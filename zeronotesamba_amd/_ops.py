@@ -3,6 +3,7 @@
 Nothing here computes: every function checks shapes, allocates outputs with torch's caching
 allocator, and enqueues HIP kernels on torch's current stream through ctypes.
 """
+import threading
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -24,7 +25,7 @@ H_IN = [96, 96, 32, 32, 8, 8, 1, 1]   # rows seen by each conv (n_bins = 96, mod
 DROP_P = 0.1                           # models.py:30
 N_BINS = 96
 
-_workspaces: Dict[Tuple[int, int], torch.Tensor] = {}
+_workspaces: Dict[Tuple[int, int, int], torch.Tensor] = {}
 
 
 def require_device(t: torch.Tensor, what: str) -> None:
@@ -71,8 +72,10 @@ def same_device(ref: torch.Tensor, tensors, what: str) -> None:
 
 
 def workspace(nbytes: int, device: torch.device, slot: int = 0) -> torch.Tensor:
-    """Grow-only scratch buffer per (device, slot).  slot lets two users overlap safely."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), slot)
+    """Grow-only scratch buffer per (device, CURRENT STREAM of that device, slot): kernels of one stream run in order and
+    may share scratch, two streams never do (a forward on a side stream gets its own buffer instead of silently
+    overwriting the default stream's split-K slabs and spectra).  slot separates users inside one stream."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream_ptr(device), slot)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -93,23 +96,54 @@ def _pp(tensors: Sequence[torch.Tensor]):
     return _lib.ptr_array([t.data_ptr() for t in tensors])
 
 
-def packed_weights(li: int, transposed: bool, nbr: int, B: int, T: int, w: Sequence[torch.Tensor],
-                   trust: bool = False) -> Optional[torch.Tensor]:
-    """The kernel-order operand of layer li's weights (zns_conv2d_pack_f32), rebuilt only when a weight tensor changed.
+class _Frozen(threading.local):
+    depth = 0
+    touched: Optional[list] = None
 
-    The frequency-domain kernels read 96 real operators per branch built from the DFT of the time taps (5-7x the weights:
-    0.5 GB per pass over the five layers); the reference's eval paths (val_epoch pretext.py:527-592, inference
-    sample_script.py:46-48) call the model many times with the SAME weights, so the operand is cached: on the first
-    branch's weight Parameter itself (it dies with the model), keyed by the library's layout id (layer, tile variant,
-    kernel family) and the tensors' addresses, validated by their autograd version counters.  Everything in this package
-    that writes parameters through a raw pointer (the fused Adam kernels) bumps those counters.
 
-    `trust`: the cached operand is only reused where the caller is NOT training (no parameter needs a gradient:
-    `torch.no_grad()` / `inference_mode` / frozen weights -- val_epoch, inference loops, PretextTrainer.evaluate); a
-    training pass rebuilds it on every call, the weights change every step anyway.  Reason: a write through `param.data`
-    (old-style manual SGD, `p.data.clamp_()`) does not bump the version counter -- the same blind spot autograd itself
-    has -- and must never train on stale weights.  Between two inference forwards such a write needs
-    `invalidate_packed(model)`."""
+_frozen = _Frozen()
+
+
+class frozen_weights:
+    """`with frozen_weights():` -- the caller's promise that no weight is written inside the block other than by something
+    that bumps the tensors' autograd version counters (any torch optimizer or in-place op on the Parameter; this package's
+    fused Adam kernels bump them explicitly).  Inside it the kernel-order weight operands (zns_conv2d_pack_f32: 0.5 GB per
+    pass over cv2..cv6 at B = 16) are built once per weight version and reused from call to call; OUTSIDE it every call
+    packs into its workspace and nothing is cached, so a write the counters cannot see (`p.data.mul_()`, EMA on `.data`,
+    a raw-pointer write) can never be served stale weights -- the round-2 cache inferred "not training" from the grad mode
+    and had exactly that blind spot.  The operands live as long as the OUTERMOST block: leaving it drops them (and their
+    memory).  val_epoch (pretext.py / epochs.py), PretextTrainer.evaluate_epoch and a frozen-backbone train_epoch hold it
+    around their own loops; an inference loop (sample_script.py:46-48 over many files) opts in explicitly.
+    Per thread; re-entrant."""
+
+    def __enter__(self):
+        if _frozen.depth == 0:
+            _frozen.touched = []
+        _frozen.depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        _frozen.depth -= 1
+        if _frozen.depth == 0:
+            for p in _frozen.touched or ():
+                p.__dict__.pop("_zns_pack", None)
+            _frozen.touched = None
+        return False
+
+
+def weights_frozen() -> bool:
+    return _frozen.depth > 0
+
+
+def packed_weights(li: int, transposed: bool, nbr: int, B: int, T: int, w: Sequence[torch.Tensor]) -> Optional[torch.Tensor]:
+    """The kernel-order operand of layer li's weights, or None (the C side then packs into the call's workspace).
+
+    Only inside a `frozen_weights()` block is an operand cached: on the first branch's weight Parameter, keyed by the
+    library's layout id (layer, tile variant, kernel family) and the tensors' addresses, validated by their autograd
+    version counters (a second guard: an optimizer step inside the block still rebuilds), dropped when the outermost
+    block exits."""
+    if not weights_frozen():
+        return None
     name, cin, cout, kh, kw, pool = LAYERS[li]
     L = _lib.lib()
     lid = _lib.C.c_int(0)
@@ -119,9 +153,12 @@ def packed_weights(li: int, transposed: bool, nbr: int, B: int, T: int, w: Seque
             return None
         key = (int(transposed), lid.value, nbr) + tuple(t.data_ptr() for t in w)
         sig = tuple(t._version for t in w)
-        cache = w[0].__dict__.setdefault("_zns_pack", {})
+        cache = w[0].__dict__.get("_zns_pack")
+        if cache is None:
+            cache = w[0].__dict__["_zns_pack"] = {}
+            _frozen.touched.append(w[0])
         hit = cache.get(key)
-        if trust and hit is not None and hit[0] == sig:
+        if hit is not None and hit[0] == sig:
             return hit[1]
         buf = hit[1] if hit is not None else torch.empty(nbytes // 4, dtype=torch.float32, device=w[0].device)
         same_device(w[0], w, name)
@@ -133,9 +170,12 @@ def packed_weights(li: int, transposed: bool, nbr: int, B: int, T: int, w: Seque
 
 
 def invalidate_packed(module: torch.nn.Module) -> None:
-    """Drop every cached packed operand of `module`'s parameters (after writing weights through `.data` or a raw pointer)."""
+    """Drop every cached packed operand of `module`'s parameters (inside a frozen_weights() block, after writing weights
+    through `.data` or a raw pointer)."""
     for p in module.parameters():
-        p.__dict__.pop("_zns_pack", None)
+        c = p.__dict__.get("_zns_pack")
+        if c is not None:
+            c.clear()
 
 
 def bump_version(t: torch.Tensor) -> None:
@@ -144,8 +184,7 @@ def bump_version(t: torch.Tensor) -> None:
 
 
 def conv_fwd(li: int, nbr: int, B: int, T: int, x: torch.Tensor, w: Sequence[torch.Tensor],
-             b: Sequence[torch.Tensor], drop_p: float, seed: int, want_argmax: bool, ws: torch.Tensor,
-             trust_packed: bool = False):
+             b: Sequence[torch.Tensor], drop_p: float, seed: int, want_argmax: bool, ws: torch.Tensor):
     name, cin, cout, kh, kw, pool = LAYERS[li]
     H = H_IN[li]
     y = torch.empty((nbr * B, cout, H // pool, T), dtype=torch.float32, device=x.device)
@@ -159,7 +198,7 @@ def conv_fwd(li: int, nbr: int, B: int, T: int, x: torch.Tensor, w: Sequence[tor
         if nspec:
             spec = torch.empty(nspec // 4, dtype=torch.float32, device=x.device)
     same_device(x, (*w, *b, ws), name)
-    wpk = packed_weights(li, False, nbr, B, T, w, trust_packed)
+    wpk = packed_weights(li, False, nbr, B, T, w)
     with on_device(x):
         rc = _lib.lib().zns_conv2d_fwd_f32(nbr, B, T, cin, cout, kh, kw, H, pool, x.data_ptr(), _pp(w), _pp(b),
                                            y.data_ptr(), am.data_ptr() if am is not None else None,
@@ -278,7 +317,8 @@ class StackParams:
 def stack_forward(x: torch.Tensor, P: StackParams, B: int, drop_p: float, seed: int, save: bool,
                   with_head: bool = True, ws_slot: int = 0):
     """x: [nbr*B, 1, 96, T] -> (emb [nbr*B, T] or None, acts [y1..y8], argmax {layer: u8}).
-    save=False is the inference form (nothing kept for a backward pass): only then are cached packed weights reused."""
+    save=False is the inference form (nothing kept for a backward pass).  Packed weight operands are reused only inside
+    a frozen_weights() block."""
     nbr = P.nbr
     T = x.shape[-1]
     with on_device(x):
@@ -287,10 +327,7 @@ def stack_forward(x: torch.Tensor, P: StackParams, B: int, drop_p: float, seed: 
     argm: Dict[int, torch.Tensor] = {}
     cur = x
     for li in range(8):
-        # inference, or this layer's weights are frozen (loader.py:30-34): nothing updates them between calls
-        trust = not save or not any(w.requires_grad for w in P.conv_w[li])
-        y, am, spec = conv_fwd(li, nbr, B, T, cur, P.conv_w[li], P.conv_b[li], drop_p, seed, save, ws,
-                               trust_packed=trust)
+        y, am, spec = conv_fwd(li, nbr, B, T, cur, P.conv_w[li], P.conv_b[li], drop_p, seed, save, ws)
         if save:
             acts.append(y)
             if am is not None:

@@ -1,5 +1,7 @@
 // extern "C" entry points for the conv layers + error plumbing (see include/zns.h).
 #include <stdarg.h>
+
+#include <mutex>
 #include <string.h>
 
 #include "zns_common.h"
@@ -8,7 +10,8 @@
 namespace zns {
 
 static thread_local char g_err[512] = "";
-static int g_impl = ZNS_IMPL_AUTO;
+static thread_local int g_impl = ZNS_IMPL_AUTO;   // per calling thread: a test selecting the naive kernels does not
+                                                    // redirect another thread's launches
 Probe g_probe;
 
 void set_error(const char* fmt, ...) {
@@ -42,12 +45,21 @@ int zns_set_impl(int impl) {
     return prev;
 }
 
+static std::mutex g_probe_mu;
 int zns_probe_arm(int kind, int cin, int cout, int kh, void* const* ev_start, void* const* ev_stop, int n) {
+    std::lock_guard<std::mutex> lock(g_probe_mu);
+    if (g_probe.n > 0 && (n > 0 || g_probe.owner != std::this_thread::get_id())) {
+        set_error("probe_arm: %s", n > 0 ? "a probe is already armed (disarm it first: n = 0)"
+                                         : "only the thread that armed the probe may disarm it");
+        return ZNS_ERR_ARG;
+    }
     delete[] g_probe.start;
     delete[] g_probe.stop;
     g_probe = Probe{};
     if (n <= 0) return ZNS_OK;
+    if (ev_start == nullptr || ev_stop == nullptr) { set_error("probe_arm: null event arrays"); return ZNS_ERR_ARG; }
     g_probe.kind = kind; g_probe.cin = cin; g_probe.cout = cout; g_probe.kh = kh; g_probe.n = n;
+    g_probe.owner = std::this_thread::get_id();
     g_probe.start = new hipEvent_t[n];
     g_probe.stop = new hipEvent_t[n];
     for (int i = 0; i < n; ++i) { g_probe.start[i] = (hipEvent_t)ev_start[i]; g_probe.stop[i] = (hipEvent_t)ev_stop[i]; }

@@ -84,6 +84,22 @@ struct ConvCfg {
     static_assert(CK * PS * 4 < 65536, "ds_read immediate range");
 };
 
+// Identifier of the packed-weight layout a configuration streams: everything pack_weights_kernel /
+// pack_freq_weights_kernel take from the configuration (COB, CK, MT, WM) plus the layer geometry, the kernel family and
+// the operator orientation.  Two configurations may share a packed operand exactly when these ids are equal, so the id is
+// COMPUTED from the constants, never listed by hand.
+template <class C>
+constexpr int pack_layout_id(int family /* 1 = frequency domain, 2 = direct */, int transposed) {
+    static_assert(C::COB / 32 < 16 && C::CK < 128 && C::MT < 8 && C::WM < 16 && C::CIN / 32 < 16 && C::COUT / 32 < 16, "id fields");
+    return (family << 29) | ((transposed ? 1 : 0) << 28) | ((C::KH > 1 ? 1 : 0) << 27) | ((C::COB / 32) << 23) |
+           (C::CK << 16) | (C::MT << 13) | (C::WM << 9) | ((C::CIN / 32) << 5) | (C::COUT / 32);
+}
+template <class A, class B>
+constexpr bool same_pack_layout() {
+    return A::COB == B::COB && A::CK == B::CK && A::MT == B::MT && A::WM == B::WM && A::CIN == B::CIN &&
+           A::COUT == B::COUT && A::KH == B::KH && A::KW == B::KW;
+}
+
 struct CoreArgs {
     const float* x;        // [N, CIN, H, T]
     const float* wpk;      // packed weights, branch stride = COUT*CIN*KH*KW

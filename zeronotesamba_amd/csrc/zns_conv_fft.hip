@@ -839,16 +839,13 @@ int fft_dgrad(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, const float
 // The frequency-weight layout depends on the tile variant (COB, CK, MT, WM), which the dispatcher picks from T: a packed
 // operand may be reused by any call whose layout id is the same.
 int fft_pack_layout(const ConvArgs& a, int transposed) {
-    const int l = fft_layer_of(a);
-    if (l < 0) return 0;
-    int narrow = 0;
+    if (fft_layer_of(a) < 0) return 0;
+    int id = 0;
     with_cfg(a, transposed, [&](auto t) {
-        typedef typename decltype(t)::type C;
-        narrow = (std::is_same<C, FF3a>::value || std::is_same<C, FF4a>::value || std::is_same<C, FF5a>::value ||
-                  std::is_same<C, FF6a>::value || std::is_same<C, FD3a>::value || std::is_same<C, FD5a>::value) ? 1 : 0;
+        id = pack_layout_id<typename decltype(t)::type>(1, transposed);
         return ZNS_OK;
     });
-    return 100 + 4 * l + 2 * narrow + (transposed ? 1 : 0);
+    return id;
 }
 size_t fft_pack_bytes(const ConvArgs& a, int transposed) {
     (void)transposed;

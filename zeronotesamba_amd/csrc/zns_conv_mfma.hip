@@ -211,9 +211,27 @@ int mfma_dgrad(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, const floa
     return ZNS_ERR_ARG;
 }
 
+// mfma_pack packs for the wide configuration of a layer; the few-workgroup variants of cv7 / cv8 must stream that operand
+static_assert(same_pack_layout<F7, F7s>() && same_pack_layout<F8, F8s>() && same_pack_layout<D7, D7s>() &&
+              same_pack_layout<D8, D8s>(), "the *s variants reuse the wide variants' packed operand");
 int mfma_pack_layout(const ConvArgs& a, int transposed) {
-    const int l = layer_of(a);
-    return l > 0 ? 200 + 2 * l + (transposed ? 1 : 0) : 0;
+    switch (layer_of(a) * 2 + (transposed ? 1 : 0)) {
+        case 4: return pack_layout_id<F2>(2, 0);
+        case 5: return pack_layout_id<D2>(2, 1);
+        case 6: return pack_layout_id<F3>(2, 0);
+        case 7: return pack_layout_id<D3>(2, 1);
+        case 8: return pack_layout_id<F4>(2, 0);
+        case 9: return pack_layout_id<D4>(2, 1);
+        case 10: return pack_layout_id<F5>(2, 0);
+        case 11: return pack_layout_id<D5>(2, 1);
+        case 12: return pack_layout_id<F6>(2, 0);
+        case 13: return pack_layout_id<D6>(2, 1);
+        case 14: return pack_layout_id<F7>(2, 0);
+        case 15: return pack_layout_id<D7>(2, 1);
+        case 16: return pack_layout_id<F8>(2, 0);
+        case 17: return pack_layout_id<D8>(2, 1);
+    }
+    return 0;
 }
 size_t mfma_pack_bytes(const ConvArgs& a, int transposed) { (void)transposed; return layer_of(a) > 0 ? packed_bytes(a) : 0; }
 int mfma_pack(const ConvArgs& a, Ptr2 w, int transposed, float* dst, hipStream_t st) {

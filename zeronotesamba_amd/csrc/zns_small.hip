@@ -451,7 +451,9 @@ size_t zns_ntxent_workspace_bytes(int rows) {
 
 int zns_ntxent_f32(const float* a, const float* p, int rows, int D, int batch_len, float tau, float* out3, float* ga,
                    float* gp, float grad_scale, void* ws, size_t ws_bytes, void* stream) {
-    ZNS_CHECK_ARG(rows >= 1 && rows <= 32768, "ntxent: rows=%d", rows);
+    // the log-softmax pass is ONE workgroup (a thread per row, O(rows^2)): sized for batch sizes the reference can hold
+    // (config.yaml batch_size 16; a 2048-row batch is already 3 x 16 MB of scratch), refused beyond
+    ZNS_CHECK_ARG(rows >= 1 && rows <= 2048, "ntxent: rows=%d (supported: 1..2048)", rows);
     ZNS_CHECK_ARG(D >= 1 && batch_len >= 2 && rows <= batch_len, "ntxent: bad D/batch_len");
     if (ws == nullptr || ws_bytes < zns_ntxent_workspace_bytes(rows)) {
         set_error("ntxent: workspace %zu < %zu", ws_bytes, zns_ntxent_workspace_bytes(rows));

@@ -47,9 +47,11 @@ def shard_units(n_units: int, rank: int, world: int, drop_last: bool = True) -> 
 
 
 def broadcast_tensors(tensors: Sequence[torch.Tensor], src: int = 0, group: Any = None) -> None:
-    """Overwrite every rank's `tensors` with rank `src`'s (replica initialisation: parameters, Adam moments)."""
+    """Overwrite every rank's `tensors` with those of the group's rank `src` (replica initialisation: parameters, Adam
+    moments).  `src` is a rank INSIDE `group`; torch.distributed.broadcast wants the global rank."""
+    gsrc = dist.get_global_rank(group, src) if group is not None else src
     for t in tensors:
-        dist.broadcast(t, src=src, group=group)
+        dist.broadcast(t, src=gsrc, group=group)
 
 
 def make_buckets(layer_slices: Sequence[Tuple[str, int, int]], min_floats: int) -> List[Tuple[str, int, int]]:

@@ -5,6 +5,7 @@
 The beat-picking evaluation the reference runs afterwards (madmom DBN + mir_eval, epochs.py:83-91)
 is CPU post-processing outside this package's scope: pass `evaluate=callable` to plug it back in.
 """
+import contextlib
 from typing import Any, Callable, Dict, List, Optional, Tuple
 
 import torch
@@ -63,9 +64,20 @@ def train_epoch(model: torch.nn.Module, criterion: Callable, optimizer: torch.op
     """epochs.py:8-101.  Returns (model, optimizer, mean loss, f_measure, cmlc, cmlt, amlc, amlt, info_gain);
     the six metrics are 0.0 unless `evaluate(cpu_output, times, threshold=..., librosa=...)` is supplied."""
     device = next(model.parameters()).device
+    model.train()
+    # frozen backbone (loader.py:29-34): the optimizer only ever touches fc1, whose weights no kernel packs -- the conv
+    # operands (forward and backward-data) are then built once for the whole epoch
+    convs = [p for n, p in model.named_parameters() if ".pretrained." in n or n.startswith("pretrained.")]
+    scope = _ops.frozen_weights() if convs and not any(p.requires_grad for p in convs) else contextlib.nullcontext()
+    with scope:
+        return _train_loop(model, criterion, optimizer, _status, indices, real_times, inputs, masks, threshold, librosa,
+                           evaluate, device)
+
+
+def _train_loop(model, criterion, optimizer, _status, indices, real_times, inputs, masks, threshold, librosa, evaluate,
+                device):
     full_loss = 0.0
     metrics = [0.0] * 6
-    model.train()
     batch_idx = -1
     for batch_idx, wav in enumerate(indices):
         times = real_times[wav]
@@ -106,7 +118,7 @@ def val_epoch(model: torch.nn.Module, criterion: Callable, _status: str, indices
     metrics = [0.0] * 6
     model.eval()
     batch_idx = -1
-    with torch.no_grad():
+    with torch.no_grad(), _ops.frozen_weights():     # no weight changes inside this loop: operands packed once per epoch
         for batch_idx, wav in enumerate(indices):
             times = real_times[wav]
             if _status == "pretrained":

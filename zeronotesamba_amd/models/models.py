@@ -26,7 +26,7 @@ def _fresh_seed() -> int:
 def _apply_stack(x, nbr, B, drop_p, seed, with_head, *params):
     """_StackFn.apply with the caller's grad mode passed in (autograd switches it off inside forward(), and
     ctx.needs_input_grad only reflects requires_grad): under torch.no_grad() -- val_epoch, inference -- nothing is saved
-    for a backward pass and the cached packed weights are reused."""
+    for a backward pass."""
     return _StackFn.apply(x, nbr, B, drop_p, seed, with_head, torch.is_grad_enabled(), *params)
 
 

@@ -80,7 +80,8 @@ def val_epoch(model: torch.nn.Module, val_loader: Iterable, criterion: NTXent,
     acc = torch.zeros(3, dtype=torch.float64, device=device1)
     model.eval()
     batch_idx = -1
-    with torch.no_grad():
+    # nothing writes the weights inside this loop: the packed weight operands are built once for the whole epoch
+    with torch.no_grad(), _ops.frozen_weights():
         for batch_idx, [batch] in enumerate(val_loader):
             anchors, postves = split_batch(batch, device0, device1)
             if optimizer is not None:
@@ -337,17 +338,26 @@ class PretextTrainer:
         if self.reducer is not None:
             self.reducer.wait()
         if update:
-            self.step_count += 1
+            self.apply_update(1.0 / self.world)
+        return out3
+
+    def apply_update(self, grad_scale: float = 1.0) -> None:
+        """ONE fused Adam launch over the flat buffers with the gradient read as `grad_scale * flat_g` (1/world after a
+        summing all-reduce; 1/k after accumulating k batches with step(update=False))."""
+        self.step_count += 1
+        dev = self.flat_p.device
+        with _ops.on_device(self.flat_p):
             rc = _lib.lib().zns_adam_step_f32(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
                                               self.flat_v.data_ptr(), self.n_flat, self.lr, self.betas[0],
-                                              self.betas[1], self.eps, self.step_count, 1.0 / self.world,
-                                              _ops.stream_ptr(x.device))
-            _lib.check(rc, "zns_adam_step_f32")
-            self._params_written()
-        return out3
+                                              self.betas[1], self.eps, self.step_count, float(grad_scale),
+                                              _ops.stream_ptr(dev))
+        _lib.check(rc, "zns_adam_step_f32")
+        self._params_written()
 
     @torch.no_grad()
     def evaluate(self, x: torch.Tensor) -> torch.Tensor:
+        """(loss, mean pos cos, mean neg cos) of one branch-major batch without dropout and without a backward pass.
+        Inside a `_ops.frozen_weights()` block (evaluate_epoch holds one) the packed weight operands are reused."""
         B = x.shape[0] // 2
         T = x.shape[-1]
         _ops.same_device(self.flat_p, (x,), "PretextTrainer.evaluate")
@@ -355,6 +365,18 @@ class PretextTrainer:
         out3 = torch.empty(3, dtype=torch.float32, device=x.device)
         _ops.ntxent(emb[:B], emb[B:], B, T, self.batch_len, self.temperature, out3, None, None)
         return out3
+
+    def evaluate_epoch(self, loader: Iterable) -> Tuple[float, float, float]:
+        """Fused equivalent of pretext.val_epoch (pretext.py:527-592): mean (loss, pos cos, neg cos) over the loader."""
+        acc = torch.zeros(3, dtype=torch.float64, device=self.flat_p.device)
+        n = 0
+        with _ops.frozen_weights():
+            for item in loader:
+                x = item if torch.is_tensor(item) else self.stack_inputs(item[0])
+                acc += self.evaluate(x).double()
+                n += 1
+        l, p, ng = (acc / max(n, 1)).tolist()
+        return l, p, ng
 
     def train_epoch(self, loader: Iterable) -> Tuple[float, float, float]:
         """Fused equivalent of pretext.train_epoch: returns (mean loss, mean pos cos, mean neg cos).
