@@ -47,12 +47,13 @@ extern "C" {
 
 const char* zns_last_error(void);
 int zns_version(void);
-/* TEST / BENCH ONLY.  Select the kernel family for the CALLING THREAD's conv fwd/dgrad/wgrad calls (thread-local, so a
- * validation run on the naive kernels cannot redirect another thread's launches).  Returns the previous value. */
+/* TEST / BENCH ONLY -- never call it from a serving or training process.  Selects the kernel family for every later conv
+ * fwd/dgrad/wgrad call of the PROCESS (process-wide on purpose: autograd runs backward() on its own thread, which must
+ * launch the family a validation test selected on the Python thread).  Returns the previous value. */
 int zns_set_impl(int impl);
 
-/* TEST / BENCH ONLY.  One probe per process, owned by the arming thread: only that thread's launches are recorded;
- * arming while a probe is armed, or disarming from another thread, returns ZNS_ERR_ARG.
+/* TEST / BENCH ONLY.  One probe per process: arming while a probe is armed, or disarming from a thread other than the
+ * one that armed it, returns ZNS_ERR_ARG.
  * Measurement hook for bench.py: record hipEvents immediately around the MAIN kernel of the next
  * conv launches that match (kind, cin, cout, kh).  kind: 0 forward, 1 backward-data, 2 backward-weights.
  * ev_start/ev_stop: host arrays of n hipEvent_t (created with timing enabled); launch i uses slot

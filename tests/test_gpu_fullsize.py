@@ -249,7 +249,7 @@ def test_finetune_step_full_size_against_the_cpu_oracle(red):
     from zeronotesamba_amd.loader import load_models
     T, lr = 1876, 0.5 * 1e-5 * 10e-2
     torch.set_num_threads(host_threads())
-    sd = cnn_ref.synth_state_dict(7, 2.0)
+    sd = cnn_ref.synth_state_dict(5, 2.0)      # with these weights the anchor branch wins a quarter of the frames of max()
     with contextlib.redirect_stdout(io.StringIO()):
         crit, opt, d = load_models("pretrained", "finetune", 1e-5, state_dict=sd, device=DEV)
     d.reduction = red
@@ -284,6 +284,7 @@ def test_finetune_step_full_size_against_the_cpu_oracle(red):
     assert abs(loss.item() - rl) < 2e-5
     assert (o.detach().cpu() - ro).abs().max().item() < 1e-4
     ref = op.grads()
+    assert all(float(g.abs().max()) > 0 for g in grads.values())          # both branches receive gradient
     worst = 0.0
     for k in grads:
         e = grad_err(k, grads[k], ref)

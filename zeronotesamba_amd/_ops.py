@@ -96,9 +96,12 @@ def _pp(tensors: Sequence[torch.Tensor]):
     return _lib.ptr_array([t.data_ptr() for t in tensors])
 
 
-class _Frozen(threading.local):
+class _Frozen:
+    """Process-wide on purpose: autograd runs `backward` on its own device thread, which must see the scope the caller
+    opened on the Python thread."""
     depth = 0
     touched: Optional[list] = None
+    lock = threading.RLock()
 
 
 _frozen = _Frozen()
@@ -114,20 +117,22 @@ class frozen_weights:
     and had exactly that blind spot.  The operands live as long as the OUTERMOST block: leaving it drops them (and their
     memory).  val_epoch (pretext.py / epochs.py), PretextTrainer.evaluate_epoch and a frozen-backbone train_epoch hold it
     around their own loops; an inference loop (sample_script.py:46-48 over many files) opts in explicitly.
-    Per thread; re-entrant."""
+    Process-wide (autograd's backward thread sees it); re-entrant."""
 
     def __enter__(self):
-        if _frozen.depth == 0:
-            _frozen.touched = []
-        _frozen.depth += 1
+        with _frozen.lock:
+            if _frozen.depth == 0:
+                _frozen.touched = []
+            _frozen.depth += 1
         return self
 
     def __exit__(self, *exc):
-        _frozen.depth -= 1
-        if _frozen.depth == 0:
-            for p in _frozen.touched or ():
-                p.__dict__.pop("_zns_pack", None)
-            _frozen.touched = None
+        with _frozen.lock:
+            _frozen.depth -= 1
+            if _frozen.depth == 0:
+                for p in _frozen.touched or ():
+                    p.__dict__.pop("_zns_pack", None)
+                _frozen.touched = None
         return False
 
 
@@ -153,10 +158,13 @@ def packed_weights(li: int, transposed: bool, nbr: int, B: int, T: int, w: Seque
             return None
         key = (int(transposed), lid.value, nbr) + tuple(t.data_ptr() for t in w)
         sig = tuple(t._version for t in w)
-        cache = w[0].__dict__.get("_zns_pack")
-        if cache is None:
-            cache = w[0].__dict__["_zns_pack"] = {}
-            _frozen.touched.append(w[0])
+        with _frozen.lock:
+            if _frozen.touched is None:        # the scope closed on another thread meanwhile
+                return None
+            cache = w[0].__dict__.get("_zns_pack")
+            if cache is None:
+                cache = w[0].__dict__["_zns_pack"] = {}
+                _frozen.touched.append(w[0])
         hit = cache.get(key)
         if hit is not None and hit[0] == sig:
             return hit[1]

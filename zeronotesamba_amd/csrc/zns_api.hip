@@ -1,6 +1,7 @@
 // extern "C" entry points for the conv layers + error plumbing (see include/zns.h).
 #include <stdarg.h>
 
+#include <atomic>
 #include <mutex>
 #include <string.h>
 
@@ -10,8 +11,8 @@
 namespace zns {
 
 static thread_local char g_err[512] = "";
-static thread_local int g_impl = ZNS_IMPL_AUTO;   // per calling thread: a test selecting the naive kernels does not
-                                                    // redirect another thread's launches
+static std::atomic<int> g_impl{ZNS_IMPL_AUTO};   // process-wide ON PURPOSE: autograd runs backward() on its own thread, which
+                                                  // must launch the family the test selected on the Python thread
 Probe g_probe;
 
 void set_error(const char* fmt, ...) {
@@ -40,9 +41,7 @@ extern "C" {
 const char* zns_last_error(void) { return g_err; }
 int zns_version(void) { return 104; }   // 101: dzspec_out / dzspec, 102: stem mix + RMS gate, 103: NT-Xent workspace (any batch size), 104: packed-weight hand-off, staged xqt, multi-tensor Adam
 int zns_set_impl(int impl) {
-    const int prev = g_impl;
-    g_impl = impl;
-    return prev;
+    return g_impl.exchange(impl);
 }
 
 static std::mutex g_probe_mu;
@@ -119,7 +118,7 @@ int zns_conv2d_pack_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw
     Ptr2 pw{};
     for (int i = 0; i < nbr; ++i) pw.p[i] = w[i];
     hipStream_t st = (hipStream_t)stream;
-    return id < 200 ? fft_pack(a, pw, transposed, dst, st) : mfma_pack(a, pw, transposed, dst, st);
+    return conv_family(a, !transposed) == 2 ? fft_pack(a, pw, transposed, dst, st) : mfma_pack(a, pw, transposed, dst, st);
 }
 
 int zns_conv2d_fwd_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, int pool, const float* x,

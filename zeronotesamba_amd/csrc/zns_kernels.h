@@ -7,8 +7,8 @@
 namespace zns {
 
 // bench.py measurement hook (zns_probe_arm): events around the main kernel of matching launches
-// ONE probe per process, owned by the thread that armed it: only that thread's launches are recorded, arming while
-// another probe is armed is refused (zns_probe_arm).
+// ONE probe per process: arming while another probe is armed is refused, only the arming thread may disarm
+// (zns_probe_arm).  Launches from any thread match (autograd's backward thread included).
 struct Probe {
     int kind = -1, cin = 0, cout = 0, kh = 0, n = 0, count = 0;
     hipEvent_t* start = nullptr;
@@ -17,8 +17,7 @@ struct Probe {
 };
 extern Probe g_probe;
 inline bool probe_match(int kind, int cin, int cout, int kh) {
-    return g_probe.n > 0 && g_probe.kind == kind && g_probe.cin == cin && g_probe.cout == cout && g_probe.kh == kh &&
-           g_probe.owner == std::this_thread::get_id();
+    return g_probe.n > 0 && g_probe.kind == kind && g_probe.cin == cin && g_probe.cout == cout && g_probe.kh == kh;
 }
 
 struct ConvArgs {
