@@ -14,6 +14,7 @@ After the timed region (never inside `ms_per_step`) rank 0 at N=1 also measures,
   module_path_ms_per_step   the literal drop-in path: Pretext_CNN autograd + NTXent + torch.optim.Adam (pretext.py:475-492)
   xqt                       BASELINE configs[1]: generate_XQT on 32 and on 4096 resident 10 s clips
   finetune                  BASELINE configs[3]: Down_CNN + BCE + Adam on one 30 s clip, T = 1876 (epochs.py:48-63)
+  epoch_path, bank_fill     the path around the step: ShiftBank -> train_epoch at T = 313; stems -> RMS gate -> VQT -> bank
 and at N>1: comm_exposed_ms (step time with minus without the gradient all-reduce) and allreduce_bytes.
 """
 import argparse
@@ -381,6 +382,66 @@ def self_launch(n: int) -> int:
     return rc
 
 
+def measure_pipeline(dev) -> dict:
+    """The path AROUND the step, after the timed region:
+    epoch_path   pretext.py:308-330 at the reference's own tile: a resident bank of 256 clips x 626 frames, ShiftBank
+                 draws 16 start frames per clip and crops 313-frame batches on the device, PretextTrainer.train_epoch
+                 steps through them (one host sync at the end of the epoch) -- next to the same step on ONE resident
+                 T = 313 batch, i.e. what the kernels alone take.
+    bank_fill    pretext.py:143-170 for stems already in HBM: 256 files x 4 stems x 12 s -> mix -> RMS-gated random
+                 10 s crop (config.yaml: lower_p .3, upper_p 1.) -> VQT pair -> resident bank; files/s, next to the VQT
+                 kernels alone on the same 512 clips."""
+    import random
+    from zeronotesamba_amd.pretext import PretextTrainer, ShiftBank, fill_memory_bank
+    from zeronotesamba_amd.processing.input_rep import generate_XQT_batch
+    out = {}
+    n_clips, crop = 256, 313
+    g = torch.Generator(device=dev).manual_seed(7)
+    bank = (torch.randn((n_clips, 2, 96, 2 * crop), generator=g, device=dev) * 3.0 - 6.0).clamp_(-20.72, 3.0)
+    bank[:, 1] = 0.7 * bank[:, 0] + 0.3 * bank[:, 1]
+    sb = ShiftBank(bank, batch_len=B, crop=crop, device=str(dev))
+    trainer = PretextTrainer(build_model(dev), batch_len=B, temperature=TAU, lr=LR, seed=1234, train=True)
+    rng = random.Random(0)
+    trainer.train_epoch(sb.batches(range(4), rng=rng))                       # warm-up
+    torch.cuda.synchronize()
+    steps = 96
+    t0 = time.perf_counter()
+    trainer.train_epoch(sb.batches(range(steps), rng=rng))                   # ends with the epoch's one host sync
+    ep = (time.perf_counter() - t0) / steps * 1e3
+    x = sb.batch(0, rng=rng)
+    res = _timed(lambda: trainer.step(x), steps, 3)
+    out["epoch_path"] = {"frames": crop, "bank_clips": n_clips, "steps": steps, "ms_per_step": ep,
+                         "resident_batch_ms_per_step": res, "vs_resident_batch": ep / res,
+                         "audio_seconds_per_s": 1e3 / ep * B * crop * HOP / SR}
+    del trainer, sb, bank, x
+    torch.cuda.empty_cache()
+    # ---- bank fill
+    n_files, n = 256, 12 * SR
+    g = torch.Generator(device=dev).manual_seed(11)
+    drums = 0.1 * torch.randn((n_files, n), generator=g, device=dev)
+    t = torch.arange(n, device=dev) % (5 * SR)
+    gain = torch.where(t < 2 * SR, 0.6, 0.1)                                  # ~40 % of the frames pass the ratio test
+    stems = {}
+    for i in range(n_files):
+        bass = drums[i] * gain * 0.5
+        stems[f"f{i}"] = {"bass": bass, "drums": drums[i], "other": bass, "vocals": 0.01 * drums[(i + 1) % n_files]}
+    fps = [f"f{i}\n" for i in range(n_files)]
+    yml = {"clip_len": 10, "input_mode": "vqt", "lower_p": 0.3, "upper_p": 1.0}
+    fill_memory_bank(stems, fps[:64], yml, rng=random.Random(1))             # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fill_memory_bank(stems, fps, yml, rng=random.Random(2))
+    torch.cuda.synchronize()
+    fill_s = time.perf_counter() - t0
+    crops = torch.empty((2 * n_files, 10 * SR), dtype=torch.float32, device=dev).normal_(0.0, 0.1, generator=g)
+    res = torch.empty((2 * n_files, 96, 1 + 10 * SR // 256), dtype=torch.float32, device=dev)
+    xq = _timed(lambda: generate_XQT_batch(crops, SR, "vqt", out=res), 5)
+    out["bank_fill"] = {"files": n_files, "stems_per_file": 4, "seconds_per_stem": 12, "files_per_s": n_files / fill_s,
+                        "ms_total": fill_s * 1e3, "xqt_kernels_alone_ms": xq, "vs_xqt_kernels_alone": fill_s * 1e3 / xq,
+                        "audio_seconds_per_s": n_files * 2 * 10 / fill_s}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -516,6 +577,7 @@ def main():
             res["config"]["module_path_vs_fused"] = res["config"]["module_path_ms_per_step"] / res["ms_per_step"]
             res["config"]["xqt"] = measure_xqt(dev, cpu)
             res["config"]["finetune"] = measure_finetune(dev, cpu)
+            res["config"].update(measure_pipeline(dev))
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
             res["cpu_baseline"]["sample"] += ("; GPU-utilisation samplers see little on this command: the timed GPU region is "

@@ -100,3 +100,37 @@ def test_drum_anchor_positive_and_resident_bank():
     tr = pretext.PretextTrainer(Pretext_CNN().to(DEV), batch_len=4, lr=1e-6, seed=1)
     out = tr.step(sb.batch(1, rng=random.Random(2))).tolist()
     assert all(np.isfinite(out))
+
+
+def test_fill_memory_bank_group_speculation_consumes_the_reference_draws():
+    """fill_memory_bank gates several files per host synchronisation (first-draw guess, rewind on a miss).  Whatever
+    the pass rate, the crop starts and the generator state must equal the per-file reference loop's (pretext.py:66-84
+    run file after file on ONE random stream): a mix of files that pass at once, files that need several draws and
+    files that only pass after lower_p has been halved."""
+    from zeronotesamba_amd import pretext
+    from zeronotesamba_amd.processing.input_rep import generate_XQT_batch
+    n = 16000 * 12
+    tracks = {}
+    for i in range(9):
+        a, pos = gated_pair(n, seed=30 + i)
+        if i % 3 == 1:                         # in-window gain for the first 6 s only: the share of passing frames
+            t = np.arange(n)                   # (0.6 .. 0.4) now depends on the crop start -> at lower_p = 0.55 a
+            a = (pos * np.where(t < 6 * 16000, 0.6, 0.1)).astype(np.float32)   # quarter of the draws pass
+        tracks[f"f{i}"] = {"bass": a, "drums": pos}
+    fps = [f"f{i}\n" for i in (4, 0, 7, 1, 2, 8, 3, 5, 6)]                 # file lists carry the newline (pretext.py:146)
+    for lower_p in (0.2, 0.55, 2.0):
+        yml = {"clip_len": 10, "input_mode": "vqt", "lower_p": lower_p, "upper_p": 1.0}
+        # reference order of events on one stream (the oracle's loop; its own XQT is not needed here)
+        rr = random.Random(77)
+        want = [sc.drum_anchor_positive(tracks[fp.strip()], yml, lambda y, sr, m: None, rng=rr)[4] for fp in fps]
+        for fpsync in (1, 4, 32):
+            r = random.Random(77)
+            bank = pretext.fill_memory_bank(tracks, fps, yml, rng=r, chunk=4, files_per_sync=fpsync)
+            assert r.getstate() == rr.getstate(), (lower_p, fpsync)
+            assert tuple(bank.shape) == (9, 2, 96, 626)
+            for row in (0, 3, 8):
+                tr = tracks[fps[row].strip()]
+                s0 = want[row]
+                crops = torch.from_numpy(np.stack([tr["bass"][s0:s0 + 160000], tr["drums"][s0:s0 + 160000]])).to(DEV)
+                exp = generate_XQT_batch(crops, 16000, "vqt")
+                assert torch.equal(bank[row], exp), (lower_p, fpsync, row)

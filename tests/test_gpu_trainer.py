@@ -444,3 +444,23 @@ def test_checkpoint_round_trip_through_the_fused_trainer(tmp_path):
     with torch.no_grad():
         comb = d(x[:B], x[B:])
     assert torch.equal(comb, torch.maximum(a0, p0))
+
+
+def test_shift_bank_batches_use_one_index_table():
+    """ShiftBank.batches draws every clip's starts up front (as pretext.py:308-318 does before the first step) and
+    uploads them as one table: same crops, same generator state as calling batch() clip by clip."""
+    import random
+    from zeronotesamba_amd.pretext import ShiftBank
+    g = torch.Generator().manual_seed(3)
+    bank = torch.randn((5, 2, 96, 120), generator=g)
+    sb = ShiftBank(bank, batch_len=4, crop=60, device=DEV)
+    sb.shuffle_(np.random.RandomState(1))
+    r1, r2 = random.Random(9), random.Random(9)
+    got = list(sb.batches([3, 0, 4], rng=r1))
+    want = [sb.batch(c, rng=r2) for c in (3, 0, 4)]
+    assert r1.getstate() == r2.getstate() and len(got) == 3
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    assert list(sb.batches([], rng=r1)) == []
+    with pytest.raises(IndexError):
+        list(sb.batches([5]))

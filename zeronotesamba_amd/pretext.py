@@ -168,8 +168,33 @@ class ShiftBank:
         return out
 
     def batches(self, clips: Iterable[int], rng=None):
+        """One batch per clip, in order.  As the reference does when it materialises `new_train_bank`
+        (pretext.py:308-318: ALL clips' start frames are drawn before the first training step), the draws for every clip
+        are made up front, in clip order -- and travel to the device as ONE pinned index table, so the per-batch work on
+        the host is a single kernel launch with no host-to-device copy."""
+        clips = [int(c) for c in clips]
+        if not clips:
+            return
         for c in clips:
-            yield self.batch(int(c), rng=rng)
+            if not 0 <= c < self.n_clips:
+                raise IndexError(f"clip {c} out of range [0, {self.n_clips})")
+        bl = self.batch_len
+        table = torch.empty((len(clips), 2, bl), dtype=torch.int32, pin_memory=True)
+        tn = table.numpy()
+        for i, c in enumerate(clips):
+            tn[i, 0, :] = int(self.order[c])
+            tn[i, 1, :] = self.draw_starts(rng)
+        dev = self.bank.device
+        dtab = table.to(dev, non_blocking=True)
+        L = _lib.lib()
+        for i in range(len(clips)):
+            out = torch.empty((2 * bl, 1, _ops.N_BINS, self.crop), dtype=torch.float32, device=dev)
+            with _ops.on_device(self.bank):
+                rc = L.zns_shift_gather_f32(self.bank.data_ptr(), self.bank_T, dtab[i, 0].data_ptr(),
+                                            dtab[i, 1].data_ptr(), bl, self.crop, out.data_ptr(), _ops.stream_ptr(dev))
+            _lib.check(rc, "zns_shift_gather_f32")
+            out._zns_keep = (dtab, table)     # the index table must outlive the enqueued kernels
+            yield out
 
 
 class PretextTrainer:
@@ -469,31 +494,84 @@ def drum_anchor_positive(stems: Dict[str, Any], ymldict, rng=None):
     return anchor.cpu().numpy(), pos.cpu().numpy(), xqt[0].cpu().numpy(), xqt[1].cpu().numpy()
 
 
+def _first_pass(count: int, n_frames: int, lower_p: float, upper_p: float) -> bool:
+    return lower_p < count / n_frames <= upper_p            # stem_check.py:47-51, first try (no halving yet)
+
+
 def fill_memory_bank(all_stems: Dict[str, Dict[str, Any]], fps: Sequence[str], ymldict, rng=None,
-                     chunk: int = 256) -> torch.Tensor:
+                     chunk: int = 256, files_per_sync: int = 32) -> torch.Tensor:
     """The bank-filling loop of create_memory_bank (pretext.py:143-170) for stems that are already loaded:
     one (anchor, positive) XQT pair per file path, in `fps` order, written straight into a device-resident
-    `(len(fps), 2, 96, T)` bank (feed it to ShiftBank).  Audio decoding and the pickle dump are out of scope."""
+    `(len(fps), 2, 96, T)` bank (feed it to ShiftBank).  Audio decoding and the pickle dump are out of scope.
+
+    The reference consumes ONE random stream across files (each file draws `randint(0, stop)` until its crop passes the
+    RMS gate), so file i+1's draws depend on how many file i needed.  To keep that stream exact without one host
+    round trip per file, `files_per_sync` files are gated per synchronisation under the guess that each passes at its
+    FIRST draw: their stems are mixed, their first candidates gated (asynchronous launches) and all counts read back
+    at once.  Files up to the first miss are final; the generator is rewound to just before the missing file's first
+    draw, that file runs the reference's loop (select_clip, 8 speculative candidates per launch), and the guessing
+    resumes behind it.  The draws consumed are exactly the reference's whatever the pass rate is
+    (tests/test_gpu_online.py)."""
+    import random as _random
     from .processing.input_rep import generate_XQT_batch
+    from .processing.stem_check import gate_counts
     length, mode, lower_p, upper_p = _yml(ymldict)
+    if mode not in ("vqt", "cqt"):
+        raise Exception("Mode can only be vqt or cqt!")
+    if not len(fps):
+        raise ValueError("fill_memory_bank: no file paths")
+    r = rng if rng is not None else _random
     n = length * 16000
+    T = _lib.lib().zns_xqt_frames(n)
     bank = None
     staged: Optional[torch.Tensor] = None
-    done = 0
-    for i, fp in enumerate(fps):
-        anchor, pos = mix_stems(all_stems[fp.strip()])
-        start = select_clip(anchor, pos, length, lower_p, upper_p, rng)
-        if staged is None:
-            staged = torch.empty((min(chunk, len(fps)), 2, n), dtype=torch.float32, device=anchor.device)
-        j = i - done
-        staged[j, 0].copy_(anchor[start:start + n])
-        staged[j, 1].copy_(pos[start:start + n])
-        if j + 1 == staged.shape[0] or i + 1 == len(fps):
-            xqt = generate_XQT_batch(staged[:j + 1].reshape(2 * (j + 1), n), 16000, mode)
-            if bank is None:
-                bank = torch.empty((len(fps), 2, xqt.shape[1], xqt.shape[2]), dtype=torch.float32, device=xqt.device)
-            bank[done:i + 1] = xqt.reshape(j + 1, 2, xqt.shape[1], xqt.shape[2])
-            done = i + 1
-    if bank is None:
-        raise ValueError("fill_memory_bank: no file paths")
+    mixes: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+    def mix(i):
+        if i not in mixes:
+            mixes[i] = mix_stems(all_stems[fps[i].strip()])
+        return mixes[i]
+
+    done = 0          # rows of the bank already transformed
+    nxt = 0           # next file whose crop start is still unknown
+    starts: Dict[int, int] = {}
+    while nxt < len(fps):
+        group = list(range(nxt, min(nxt + max(1, files_per_sync), len(fps))))
+        states, cands, counts, n_frames = [], [], [], 1
+        for i in group:
+            a, p = mix(i)
+            stop = a.numel() - n - 1
+            if stop < 0:
+                raise ValueError(f"signal of {a.numel()} samples is shorter than a {length} s clip")
+            states.append(r.getstate())
+            cands.append(r.randint(0, stop))
+            c, n_frames, _, _ = gate_counts(a, p, [cands[-1]], n)
+            counts.append(c)
+        got = torch.cat(counts).tolist()                                  # the one synchronisation of this group
+        for j, i in enumerate(group):
+            if _first_pass(got[j], n_frames, lower_p, upper_p):
+                starts[i] = cands[j]
+                nxt = i + 1
+                continue
+            r.setstate(states[j])                                         # a miss: this file runs the reference's loop
+            a, p = mix(i)
+            starts[i] = select_clip(a, p, length, lower_p, upper_p, r)
+            nxt = i + 1
+            break                                                         # later files' draws start after this one's
+        # crop every file whose start is now known into the staging buffer; transform whole chunks
+        while done < nxt:
+            if staged is None:
+                a0 = mix(done)[0]
+                staged = torch.empty((min(chunk, len(fps)), 2, n), dtype=torch.float32, device=a0.device)
+                bank = torch.empty((len(fps), 2, 96, T), dtype=torch.float32, device=a0.device)
+            lo = done - done % staged.shape[0]                            # first row of the chunk being staged
+            k = done - lo
+            a, p = mixes.pop(done)
+            st = starts.pop(done)
+            staged[k, 0].copy_(a[st:st + n])
+            staged[k, 1].copy_(p[st:st + n])
+            done += 1
+            if k + 1 == staged.shape[0] or done == len(fps):
+                generate_XQT_batch(staged[:k + 1].reshape(2 * (k + 1), n), 16000, mode,
+                                   out=bank[lo:done].view(2 * (k + 1), 96, T))
     return bank
