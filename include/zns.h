@@ -177,9 +177,19 @@ int zns_xqt_host_bank(int mode, int* n_fft8, float* fir, size_t fir_floats, doub
 int zns_xqt_f32(const float* wav, int n_clips, int n_samples, int sample_rate, int mode,
                 float* out, void* ws, size_t ws_bytes, void* stream);
 /* The same, one stage at a time (measurement and tests): stages = 1 builds the decimation pyramid in `ws`, 2 applies
- * the filter bank to the pyramid already in `ws`, 3 = both = zns_xqt_f32. */
+ * the filter bank to the pyramid already in `ws`, 3 = both = zns_xqt_f32.  With both stages the default plan is the
+ * per-stage launches; OR ZNS_XQT_MARCH into `stages` to run the second implementation instead, one persistent kernel that
+ * marches through each clip with both stages side by side (vqt only; a third of the HBM traffic, bit-identical results,
+ * not faster: see DESIGN.md section 5). */
+#define ZNS_XQT_SEPARATE 4       /* per-stage launches (decimation chains, then the filter bank) */
+#define ZNS_XQT_MARCH 8          /* the persistent marching kernel (vqt only) */
 int zns_xqt_stages_f32(const float* wav, int n_clips, int n_samples, int sample_rate, int mode,
                        float* out, void* ws, size_t ws_bytes, int stages, void* stream);
+
+/* TEST ONLY.  The pyramid divides by float32(sqrt(0.5)) as `(float)((double)x * (1 / c))`; this runs that against the
+ * float32 division over ALL 2^32 float32 bit patterns.  mismatches (device, 8 bytes) receives the count of differing
+ * results, first_bad_bits (device, 4 bytes) the smallest differing input's bits (0xFFFFFFFF: none). */
+int zns_selftest_div_sqrt_half(unsigned long long* mismatches, unsigned* first_bad_bits, void* stream);
 
 /* ------------------------------------------------------------------ shift batching (pretext.py:285-292,308-321)
  * bank: [n_bank, 2, 96, bank_T]; for item i of the batch: out[i] = bank[clip[i], :, :, start[i]:start[i]+T]

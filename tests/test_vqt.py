@@ -245,3 +245,78 @@ def test_generate_xqt_linearity_at_full_size():
     assert tuple(a.shape) == (32, 96, 626)
     # V(2y) = 2 V(y)  ->  log|V| shifts by log 2
     assert (b - a - np.log(2.0)).abs().max().item() < 2e-4
+
+
+@pytest.mark.gpu
+def test_division_by_sqrt_half_is_exact_for_every_float32():
+    """The pyramid's `y /= sqrt(0.5)` (float32) runs as one float64 multiply by 1 / float32(sqrt(0.5)) rounded once to
+    float32.  Exhaustive: all 2^32 float32 bit patterns against the float32 division."""
+    from zeronotesamba_amd import _lib
+    bad = torch.zeros(1, dtype=torch.int64, device="cuda")
+    first = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.lib().zns_selftest_div_sqrt_half(bad.data_ptr(), first.data_ptr(),
+                                                       torch.cuda.current_stream().cuda_stream), "selftest")
+    torch.cuda.synchronize()
+    assert bad.item() == 0, (bad.item(), hex(first.item() & 0xFFFFFFFF))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,clips", [(160000, 3), (80000, 5), (33333, 4), (4097, 2), (131072, 2), (20000, 600), (8192, 1)])
+def test_marching_kernel_equals_the_per_stage_launches_bitwise(n, clips):
+    """ONE persistent kernel (pyramid waves + filter-bank waves marching through each clip, several clips per workgroup
+    back to back) against the per-stage launches: the same taps in the same order with the same roundings, so every
+    output must be bit-identical -- whole 10 s clips, lengths that are odd, not multiples of a step (2048) or of a frame,
+    a power of two, a batch larger than the number of CUs (workgroups stream 2-3 clips), rows off 16-byte alignment."""
+    from zeronotesamba_amd import _lib
+    from zeronotesamba_amd.processing.input_rep import generate_XQT_batch
+    g = torch.Generator().manual_seed(n + clips)
+    y = (0.1 * torch.randn(clips, n, generator=g)).cuda()
+    y[0, : n // 3] += 0.3 * torch.sin(torch.arange(n // 3, device="cuda") * 0.2)          # make clips differ in level too
+    sep = generate_XQT_batch(y, 16000, "vqt", stages=3 | _lib.ZNS_XQT_SEPARATE)
+    mar = generate_XQT_batch(y, 16000, "vqt", stages=3 | _lib.ZNS_XQT_MARCH)
+    assert torch.equal(sep, mar), (n, clips, (sep - mar).abs().max().item())
+    if clips <= 5:
+        ref = vqt_ref.generate_XQT(y[clips - 1].cpu().numpy(), 16000, "vqt")              # and both equal the oracle
+        assert lin_err(mar[clips - 1].cpu().numpy(), ref) < 1e-5
+    if n == 33333:
+        flat = torch.cat([y.reshape(-1), y.new_zeros(8)])
+        odd = flat[1:1 + n].reshape(1, n)
+        assert odd.data_ptr() % 16 == 4
+        assert torch.equal(generate_XQT_batch(odd, 16000, "vqt", stages=3 | _lib.ZNS_XQT_MARCH),
+                           generate_XQT_batch(odd.clone(), 16000, "vqt", stages=3 | _lib.ZNS_XQT_SEPARATE))
+    if n == 160000:
+        with pytest.raises(RuntimeError, match="marching kernel"):
+            generate_XQT_batch(y[:1], 16000, "cqt", stages=3 | _lib.ZNS_XQT_MARCH)
+
+
+@pytest.mark.gpu
+def test_marching_kernel_repeats_and_survives_a_dirty_workspace():
+    """The persistent kernel keeps its state in LDS and reads pyramid rows back through L2: running it twice, and on a
+    workspace filled with NaNs, must give the same bits (nothing is read before it was written in the same launch)."""
+    from zeronotesamba_amd import _lib
+    from zeronotesamba_amd.processing.input_rep import generate_XQT_batch
+    g = torch.Generator().manual_seed(5)
+    n, clips = 48000, 260
+    y = (0.1 * torch.randn(clips, n, generator=g)).cuda()
+    M = 3 | _lib.ZNS_XQT_MARCH
+    a = generate_XQT_batch(y, 16000, "vqt", stages=M)
+    ws = torch.full((_lib.lib().zns_xqt_workspace_bytes(clips, n, 0),), 0xFF, dtype=torch.uint8, device="cuda")
+    b = generate_XQT_batch(y, 16000, "vqt", ws=ws, stages=M)
+    c = generate_XQT_batch(y, 16000, "vqt", ws=ws, stages=M)
+    assert torch.equal(a, b) and torch.equal(b, c)
+    assert torch.equal(a, generate_XQT_batch(y, 16000, "vqt"))                               # the default plan: per-stage launches
+    assert torch.equal(a[:7], generate_XQT_batch(y[:7].contiguous(), 16000, "vqt"))          # small batch: fused-tail plan
+    assert torch.isfinite(a).all()
+
+
+def test_decimation_right_wing_is_the_left_wing_shifted_by_one():
+    """resampy's kaiser_fast taps for the exact 2:1 ratio: left[i] = win(256 i), right[k] = win(256 (k + 1)) -- the kernels
+    keep only the 32 left taps in registers and read right[k] as left[k + 1]."""
+    from zeronotesamba_amd import _lib
+    taps = (_lib.C.c_double * 63)()
+    rc = _lib.lib().zns_xqt_host_bank(0, None, None, 0, taps)
+    assert rc == 0
+    t = np.array(list(taps))
+    np.testing.assert_array_equal(t[32:], t[1:32])
+    l, r = vqt_ref.decimate2_taps()                      # the oracle's own table has the same structure
+    np.testing.assert_array_equal(np.asarray(r)[:31], np.asarray(l)[1:32])

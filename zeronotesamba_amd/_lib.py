@@ -53,6 +53,7 @@ SIGNATURES = {
                                     C.POINTER(C.c_double)]),
     "zns_xqt_f32": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp, C.c_size_t, c_fp]),
     "zns_xqt_stages_f32": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp, C.c_size_t, C.c_int, c_fp]),
+    "zns_selftest_div_sqrt_half": (C.c_int, [c_fp, c_fp, c_fp]),
     "zns_shift_gather_f32": (C.c_int, [c_fp, C.c_int, c_fp, c_fp, C.c_int, C.c_int, c_fp, c_fp]),
     "zns_stem_mix_f32": (C.c_int, [c_fp, C.c_int, C.c_longlong, c_fp, c_fp]),
     "zns_rms_frames": (C.c_int, [C.c_int]),
@@ -62,6 +63,7 @@ SIGNATURES = {
 ZNS_IMPL_AUTO, ZNS_IMPL_NAIVE, ZNS_IMPL_DIRECT = 0, 1, 2
 ZNS_REDUCE_MAX, ZNS_REDUCE_MEAN = 0, 1
 ZNS_MODE_VQT, ZNS_MODE_CQT = 0, 1
+ZNS_XQT_SEPARATE, ZNS_XQT_MARCH = 4, 8
 ZNS_ERR_MODE = -3
 
 

@@ -23,7 +23,8 @@ def generate_XQT_batch(signals: torch.Tensor, sample_rate: int, mode: str, out: 
                        stages: int = 3, ws: torch.Tensor = None) -> torch.Tensor:
     """signals: float32 [n_clips, n_samples] on a ROCm device -> float32 [n_clips, 96, 1 + n_samples//256].
     out: optional preallocated result (steady-state pipelines reuse it).  stages: 3 = the whole transform; 1 / 2 run
-    the decimation pyramid / the filter bank alone on the shared workspace (bench.py times them separately).
+    the decimation pyramid / the filter bank alone on the shared workspace (bench.py times them separately); 3 runs the
+    per-stage launches, 3 | _lib.ZNS_XQT_MARCH the second implementation (one persistent marching kernel; same bits).
     ws: optional caller-owned uint8 workspace of zns_xqt_workspace_bytes (a pipeline that overlaps two batches on two
     streams gives each its own; the default is one grow-only buffer per device)."""
     if mode not in _MODES:
