@@ -179,8 +179,8 @@ int zns_xqt_f32(const float* wav, int n_clips, int n_samples, int sample_rate, i
 /* The same, one stage at a time (measurement and tests): stages = 1 builds the decimation pyramid in `ws`, 2 applies
  * the filter bank to the pyramid already in `ws`, 3 = both = zns_xqt_f32.  With both stages the default plan is the
  * per-stage launches; OR ZNS_XQT_MARCH into `stages` to run the second implementation instead, one persistent kernel that
- * marches through each clip with both stages side by side (vqt only; a third of the HBM traffic, bit-identical results,
- * not faster: see DESIGN.md section 5). */
+ * marches through each clip with both stages side by side (vqt only; less HBM traffic, bit-identical results, not faster:
+ * see DESIGN.md section 5). */
 #define ZNS_XQT_SEPARATE 4       /* per-stage launches (decimation chains, then the filter bank) */
 #define ZNS_XQT_MARCH 8          /* the persistent marching kernel (vqt only) */
 int zns_xqt_stages_f32(const float* wav, int n_clips, int n_samples, int sample_rate, int mode,

@@ -10,7 +10,7 @@
 // The default plan runs them as separate launches (decimate_chain_kernel per level or fused tail, xqt_filter_kernel).
 // xqt_march_kernel is a second implementation of the whole transform -- ONE persistent kernel that marches through each
 // clip in time order with pyramid waves and filter-bank waves side by side in every workgroup, no halo recomputation and
-// a third of the HBM traffic; bit-identical, selected with ZNS_XQT_MARCH.  It was built to overlap the two stages and
+// less HBM traffic (8-11 GB against 13 GB per 4096 clips); bit-identical, selected with ZNS_XQT_MARCH.  It was built to overlap the two stages and
 // measured: an fp32 MFMA and a vector instruction of one SIMD do not execute concurrently on gfx950, so it is not faster.
 //
 // Numerics that are restated exactly (see oracle/vqt_ref.py, which documents the recalled third-party
@@ -1153,7 +1153,7 @@ int zns_xqt_stages_f32(const float* wav, int n_clips, int n_samples, int sample_
                   "xqt: stages=%d (1 pyramid, 2 filter bank, 3 both; + ZNS_XQT_SEPARATE or ZNS_XQT_MARCH)", stages | plan_flags);
     // Both stages: the per-stage launches, unless the caller asks for the marching kernel (ZNS_XQT_MARCH; env
     // ZNS_XQT_MARCH_MIN = n makes it the plan from n clips on).  The marching kernel is the SECOND implementation of the
-    // transform (same bits, tests/test_vqt.py) and moves a third of the HBM bytes, but it is not faster: on gfx950 an fp32
+    // transform (same bits, tests/test_vqt.py) and moves fewer HBM bytes (8-11 GB against 13 GB per 4096 clips), but it is not faster: on gfx950 an fp32
     // MFMA and a vector instruction of the same SIMD do not execute together (tools/ubench_f64_mfma.hip: both = sum), so
     // there is no matrix-pipe time to hide under the float64 issue stream, and at its 2 pyramid waves per SIMD the taps run
     // slower than in the 5-waves-per-SIMD chain launches (4096 clips: 6.3 ms against 6.0 ms).
