@@ -68,11 +68,13 @@ EXEC_FLOP = exec_flop(T, 2 * B)
 # dominant kernel (profiles/): the frequency-domain forward GEMM-conv of cv4 (conv_core<128,128,1x9 taps, 12-wave HET layout>)
 PROBE = dict(kind=0, cin=128, cout=128, kh=9, name="conv_core<spectral cv4 forward: 96 real 128x1152 GEMM-convs per sample, 9 row taps>",
              flop=spectral_flop("cv4", True),
-             # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/r02f_pmc_summary.csv), NOT measured by
-             # this run: FETCH_SIZE 607 446 KB x 2 (gfx950 counts the 128-B requests of 16-byte loads as 64 B) +
-             # WRITE_SIZE 540 672 KB
+             # HBM bytes per launch from separate rocprofv3 --pmc passes, NOT measured by this run: 2 x FETCH_SIZE (gfx950
+             # counts the 128-B requests of 16-byte loads as 64 B) + WRITE_SIZE of this kernel's row in PROBE_PMC_FILE.
+             # tests/test_bench_contract.py fails when the two drift apart (a new profile set must update both).
              traffic=(2 * 607446 + 540672) * 1024.0,
-             traffic_source="constant from separate rocprofv3 --pmc passes (profiles/), 2 x FETCH_SIZE + WRITE_SIZE; not measured by this run")
+             traffic_source="constant from separate rocprofv3 --pmc passes (profiles/r02f_pmc_summary.csv), 2 x FETCH_SIZE + WRITE_SIZE; not measured by this run")
+PROBE_PMC_FILE = "profiles/r02f_pmc_summary.csv"
+PROBE_PMC_KERNEL = "conv_core<ConvCfg<128, 128, 1, 9, 1, 4, 1, 1, 1, 1, 12, 8,"      # the 12-wave HET forward / backward-data kernel of cv4
 
 
 def _lowbias32(x):

@@ -209,6 +209,12 @@ int zns_shift_gather_f32(const float* bank, int bank_T, const int32_t* clip, con
  * applies lower_p < perc <= upper_p on the host, exactly as the reference does.  rms_a / rms_p: optional device
  * outputs [n_cand][n_frames]. */
 int zns_stem_mix_f32(const float* const* stems, int n_stems, long long n, float* out, void* stream);
+/* The same mix for MANY files in one launch, cropped (the bank fill of pretext.py:143-170): `table` is a device array of
+ * n_files rows of 3 + max_other int64: [n_other (1..max_other), start, drums pointer, other-stem pointers in dict order];
+ * out[f][0][0..n) = the float32 sum of file f's other stems over [start, start + n) (same order of additions as
+ * zns_stem_mix_f32), out[f][1][0..n) = its drums stem over the same range.  out: [n_files, 2, n_samples].  The RMS gate
+ * then reads row f at start offset f * 2 * n_samples (anchor = out, positive = out + n_samples). */
+int zns_stage_crops_f32(const long long* table, int n_files, int max_other, int n_samples, float* out, void* stream);
 int zns_rms_frames(int n_samples);
 int zns_rms_gate_f32(const float* anchor, const float* positive, const long long* start, int n_cand, int n_samples,
                      float* rms_a, float* rms_p, int* pass_count, void* stream);

@@ -118,3 +118,17 @@ def test_bench_refuses_more_ranks_than_gpus_without_a_result_line():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                          capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert out.returncode != 0 and "{" not in out.stdout
+
+
+def test_roofline_traffic_constant_is_the_committed_pmc_row():
+    """`roofline.traffic` is a constant taken from separate `--pmc` passes (counters cannot ride in the timed run): it
+    must equal 2 x FETCH_SIZE + WRITE_SIZE of the probe kernel's row in the profile summary bench.py names, so that a
+    new profile set (or a changed dominant kernel) cannot leave a stale number in the bench line."""
+    import csv
+    sys.path.insert(0, ROOT)
+    import bench
+    rows = [r for r in csv.DictReader(open(os.path.join(ROOT, bench.PROBE_PMC_FILE))) if bench.PROBE_PMC_KERNEL in r["kernel"]]
+    assert len(rows) == 1, [r["kernel"] for r in rows]
+    want = (2 * float(rows[0]["FETCH_SIZE"]) + float(rows[0]["WRITE_SIZE"])) * 1024.0
+    assert abs(bench.PROBE["traffic"] - want) <= 1e-3 * want
+    assert os.path.basename(bench.PROBE_PMC_FILE) in bench.PROBE["traffic_source"]

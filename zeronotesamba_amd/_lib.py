@@ -56,6 +56,7 @@ SIGNATURES = {
     "zns_selftest_div_sqrt_half": (C.c_int, [c_fp, c_fp, c_fp]),
     "zns_shift_gather_f32": (C.c_int, [c_fp, C.c_int, c_fp, c_fp, C.c_int, C.c_int, c_fp, c_fp]),
     "zns_stem_mix_f32": (C.c_int, [c_fp, C.c_int, C.c_longlong, c_fp, c_fp]),
+    "zns_stage_crops_f32": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_fp]),
     "zns_rms_frames": (C.c_int, [C.c_int]),
     "zns_rms_gate_f32": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp]),
 }

@@ -67,7 +67,8 @@ __global__ void __launch_bounds__(256) cv1_fwd_kernel(int B, int T, int H, const
 // Weight gradient: dW[co][r][s] = sum_{n,h,t} dZ[n,co,h,t] * x[n,h+r-1,t+s-5],  db[co] = sum dZ.
 // block -> (n, h); 4 waves: wave r < 3 owns kernel row r, lane = output channel, 11 tap accumulators per lane;
 // wave 3 accumulates the bias gradient.  Per 128-step time chunk the 64 x 128 dZ tile (row stride 129: conflict-free
-// per-channel reads) and the three zero-padded input rows are staged in LDS with coalesced loads; the input window
+// per-channel reads) and the three zero-padded input rows are staged in LDS with coalesced loads (register-prefetched one
+// chunk ahead: see the loop); the input window
 // of a step is wave-uniform, i.e. LDS broadcast reads.  No cross-lane reduction at all: the block writes its
 // 34 x 64 partial sums tap-major (coalesced), cv1_wgrad_reduce adds the B*H blocks in a fixed order.
 constexpr int CW_TC = 128, CW_XS = CW_TC + 16, CW_K1 = CV1_KH * CV1_KW + 1;
@@ -83,30 +84,42 @@ __global__ void __launch_bounds__(256) cv1_wgrad_kernel(int T, int H, const floa
 #pragma unroll
     for (int s = 0; s < CV1_KW; ++s) acc[s] = 0.f;
     float bsum = 0.f;
+    // The dZ tile of chunk c + 1 (32 floats per thread) and the three input rows travel global -> registers while chunk c is
+    // being multiplied out of LDS, and registers -> LDS between the two barriers: the block no longer alternates between
+    // "all waves wait for memory" and "memory idle" (round 2: 2 TB/s of dZ reads).
+    constexpr int NZ = CV1_CO * CW_TC / 256, NX = (CV1_KH * CW_XS + 255) / 256;
+    float vz[NZ], vx[NX];
+    const float* __restrict__ dzn = dz + ((size_t)n * CV1_CO * H + h) * T;
+    auto fetch = [&](int t0) {
+#pragma unroll
+        for (int j = 0; j < NZ; ++j) {
+            const int i = threadIdx.x + j * 256;
+            const int co = i / CW_TC, tt = i % CW_TC;
+            vz[j] = (t0 + tt < T) ? dzn[(size_t)co * H * T + t0 + tt] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int i = threadIdx.x + j * 256;
+            const int r = i / CW_XS, c = i % CW_XS;
+            const int hh = h + r - 1, tt = t0 + c - 5;
+            vx[j] = (i < CV1_KH * CW_XS && hh >= 0 && hh < H && tt >= 0 && tt < T) ? x[((size_t)n * H + hh) * T + tt] : 0.f;
+        }
+    };
+    fetch(0);
     for (int t0 = 0; t0 < T; t0 += CW_TC) {
-        __syncthreads();
-        // dZ tile: 8 loads in flight per thread, 512 contiguous bytes per channel row
+        __syncthreads();                      // the previous chunk's LDS reads are done
 #pragma unroll
-        for (int u = 0; u < CV1_CO * CW_TC / 256; u += 8) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = threadIdx.x + (u + j) * 256;
-                const int co = i / CW_TC, tt = i % CW_TC;
-                v[j] = (t0 + tt < T) ? dz[(((size_t)n * CV1_CO + co) * H + h) * T + t0 + tt] : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = threadIdx.x + (u + j) * 256;
-                sdz[(i / CW_TC) * (CW_TC + 1) + (i % CW_TC)] = v[j];
-            }
+        for (int j = 0; j < NZ; ++j) {
+            const int i = threadIdx.x + j * 256;
+            sdz[(i / CW_TC) * (CW_TC + 1) + (i % CW_TC)] = vz[j];
         }
-        for (int i = threadIdx.x; i < CV1_KH * CW_XS; i += 256) {
-            const int r = i / CW_XS, j = i % CW_XS;
-            const int hh = h + r - 1, tt = t0 + j - 5;
-            sx[i] = (hh >= 0 && hh < H && tt >= 0 && tt < T) ? x[((size_t)n * H + hh) * T + tt] : 0.f;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int i = threadIdx.x + j * 256;
+            if (i < CV1_KH * CW_XS) sx[i] = vx[j];
         }
         __syncthreads();
+        if (t0 + CW_TC < T) fetch(t0 + CW_TC);   // in flight during the multiply below
         const float* zr = sdz + lane * (CW_TC + 1);
         if (wv < CV1_KH) {
             const float4* xr = reinterpret_cast<const float4*>(sx + wv * CW_XS);

@@ -357,6 +357,26 @@ __global__ void stem_mix_kernel(StemPtrs st, int n_stems, long long n, float* __
 // one wave per (frame, candidate): librosa.feature.rms(frame_length=2048, hop_length=512, center=True, reflect pad)
 // of both signals, then the two ratio tests of check_CL_clips.  Squares are float32 like np.abs(x)**2; the 2048-term
 // sum is carried in float64 and rounded once (numpy's float32 running sum differs in the last bits only).
+// Many files per launch (bank fill, pretext.py:143-170): row f of the device table is
+//   [n_other, start, drums pointer, other-stem pointers ...] (int64);
+// out[f][0][i] = stems_other[0][start + i] + stems_other[1][start + i] + ... (float32 adds in that order, the arithmetic
+// of stem_mix_kernel), out[f][1][i] = drums[start + i], i < n: the two crops the RMS gate and the XQT read.
+__global__ void __launch_bounds__(256) stage_crops_kernel(const long long* __restrict__ table, int row_len, int n,
+                                                          float* __restrict__ out) {
+    const long long* __restrict__ row = table + (size_t)blockIdx.y * row_len;
+    const int n_other = (int)row[0];
+    const long long start = row[1];
+    const float* __restrict__ drums = reinterpret_cast<const float*>(row[2]) + start;
+    float* __restrict__ oa = out + (size_t)blockIdx.y * 2 * n;
+    float* __restrict__ op = oa + n;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        float acc = reinterpret_cast<const float*>(row[3])[start + i];
+        for (int k = 1; k < n_other; ++k) acc += reinterpret_cast<const float*>(row[3 + k])[start + i];
+        oa[i] = acc;
+        op[i] = drums[i];
+    }
+}
+
 __global__ void __launch_bounds__(64) rms_gate_kernel(const float* __restrict__ a, const float* __restrict__ p,
                                                       const long long* __restrict__ start, int n_samples,
                                                       int n_frames, float* __restrict__ rms_a,
@@ -540,6 +560,17 @@ int zns_stem_mix_f32(const float* const* stems, int n_stems, long long n, float*
     for (int i = 0; i < n_stems; ++i) st.p[i] = stems[i];
     hipLaunchKernelGGL(stem_mix_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, st,
                        n_stems, n, out);
+    ZNS_LAUNCH_CHECK();
+    return ZNS_OK;
+}
+
+int zns_stage_crops_f32(const long long* table, int n_files, int max_other, int n_samples, float* out, void* stream) {
+    ZNS_CHECK_ARG(table != nullptr && out != nullptr && n_files >= 1 && max_other >= 1 && max_other <= 8 && n_samples > 0,
+                  "stage_crops: need a table, 1..8 other stems per file and n_samples > 0 (got %d files, %d, %d)", n_files,
+                  max_other, n_samples);
+    const int bx = (n_samples + 2047) / 2048;      // 8 samples per thread
+    hipLaunchKernelGGL(stage_crops_kernel, dim3((unsigned)bx, (unsigned)n_files), dim3(256), 0, (hipStream_t)stream, table,
+                       3 + max_other, n_samples, out);
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
 }

@@ -365,9 +365,6 @@ __device__ __forceinline__ void dc_taps63(const double* __restrict__ pg, const d
 
 __global__ void __launch_bounds__(256) decimate_chain_kernel(DecChain P, const DecTaps* __restrict__ tp) {
     extern __shared__ __attribute__((aligned(16))) double dwin[];     // [2][DC_WIN] (one buffer when nlev == 1)
-    double tl[32];                        // the taps: scalar registers (uniform), r[k] = l[k + 1]
-#pragma unroll
-    for (int i = 0; i < 32; ++i) tl[i] = tp->l[i];
     const int clip = blockIdx.x / P.blocks_per_clip, b = blockIdx.x - clip * P.blocks_per_clip;
     // T0[j] - 32 = 2 (T0[j+1] - 32)  ->  closed form, no runtime-indexed array
     auto T0 = [&](int j) { return 32 + (b * 4 * P.GL - 32) * (1 << (P.nlev - 1 - j)); };
@@ -403,7 +400,15 @@ __global__ void __launch_bounds__(256) decimate_chain_kernel(DecChain P, const D
         const int T0j = T0(j);
         for (int g = threadIdx.x; g < P.G[j]; g += 256) {
             double acc[4] = {0.0, 0.0, 0.0, 0.0};   // always holds a float32-representable value
-            dc_taps63<DC_S>(src + g, tl, acc);
+            // serial chunks of 8 taps (taps through the scalar cache): 48 registers, 8 waves per SIMD hide every wait.  The
+            // pipelined form the marching kernel needs (dc_taps63: 83 registers, 5 waves) measured 9 % slower here.
+            const double* p = src + g + 3;
+#pragma unroll 1
+            for (int c = 0; c < 4; ++c, --p) dc_chunk<8, true>(p, tp->l + 8 * c, acc);
+            p = src + g + 4;
+#pragma unroll 1
+            for (int c = 0; c < 3; ++c, ++p) dc_chunk<8, false>(p, tp->r + 8 * c, acc);
+            dc_chunk<7, false>(p, tp->r + 24, acc);
             const int t0 = T0j + 4 * g;
             float v[4];
 #pragma unroll

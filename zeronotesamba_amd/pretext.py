@@ -505,73 +505,111 @@ def fill_memory_bank(all_stems: Dict[str, Dict[str, Any]], fps: Sequence[str], y
     `(len(fps), 2, 96, T)` bank (feed it to ShiftBank).  Audio decoding and the pickle dump are out of scope.
 
     The reference consumes ONE random stream across files (each file draws `randint(0, stop)` until its crop passes the
-    RMS gate), so file i+1's draws depend on how many file i needed.  To keep that stream exact without one host
-    round trip per file, `files_per_sync` files are gated per synchronisation under the guess that each passes at its
-    FIRST draw: their stems are mixed, their first candidates gated (asynchronous launches) and all counts read back
-    at once.  Files up to the first miss are final; the generator is rewound to just before the missing file's first
-    draw, that file runs the reference's loop (select_clip, 8 speculative candidates per launch), and the guessing
-    resumes behind it.  The draws consumed are exactly the reference's whatever the pass rate is
+    RMS gate), so file i+1's draws depend on how many file i needed.  To keep that stream exact without a host round
+    trip -- or even a kernel launch -- per file, `files_per_sync` files are handled per synchronisation under the guess
+    that each passes at its FIRST draw: ONE launch mixes and crops all of them into the staging rows the XQT will read
+    (zns_stage_crops_f32, a pinned pointer / start table), ONE launch gates the rows, and all counts are read back at
+    once.  Files up to the first miss are final; the generator is rewound to just before the missing file's first draw,
+    that file runs the reference's loop (select_clip, 8 speculative candidates per launch) and is staged again, and the
+    guessing resumes behind it.  The draws consumed are exactly the reference's whatever the pass rate is
     (tests/test_gpu_online.py)."""
     import random as _random
     from .processing.input_rep import generate_XQT_batch
-    from .processing.stem_check import gate_counts
+    from .processing.stem_check import to_device_signal
     length, mode, lower_p, upper_p = _yml(ymldict)
     if mode not in ("vqt", "cqt"):
         raise Exception("Mode can only be vqt or cqt!")
     if not len(fps):
         raise ValueError("fill_memory_bank: no file paths")
     r = rng if rng is not None else _random
+    L = _lib.lib()
     n = length * 16000
-    T = _lib.lib().zns_xqt_frames(n)
-    bank = None
-    staged: Optional[torch.Tensor] = None
-    mixes: Dict[int, Tuple[torch.Tensor, torch.Tensor]] = {}
+    T = L.zns_xqt_frames(n)
+    n_frames = L.zns_rms_frames(n)
+    MAX_OTHER = 8
+    row_len = 3 + MAX_OTHER
+    chunk = max(1, min(chunk, len(fps)))
 
-    def mix(i):
-        if i not in mixes:
-            mixes[i] = mix_stems(all_stems[fps[i].strip()])
-        return mixes[i]
+    def signals(i):
+        """(other stems in dict order, drums) of file i as device float32 vectors (no copy when they already are)."""
+        stems = all_stems[fps[i].strip()]
+        others, drums = [], None
+        for name, sig in stems.items():
+            t = sig if (torch.is_tensor(sig) and sig.is_cuda and sig.dtype == torch.float32 and sig.dim() == 1
+                        and sig.is_contiguous()) else to_device_signal(sig, f"stem {name!r}")
+            if name == "drums":
+                drums = t
+            else:
+                others.append(t)
+        if not others:
+            raise Exception("Anchor is still None.")
+        if drums is None:
+            raise KeyError("stems has no 'drums' entry")
+        if len(others) > MAX_OTHER:
+            raise ValueError(f"more than {MAX_OTHER} non-drum stems")
+        m = drums.numel()
+        if any(o.numel() != m for o in others):
+            raise ValueError("all stems must have the same length")
+        if m - n - 1 < 0:
+            raise ValueError(f"signal of {m} samples is shorter than a {length} s clip")
+        return others, drums
 
-    done = 0          # rows of the bank already transformed
-    nxt = 0           # next file whose crop start is still unknown
-    starts: Dict[int, int] = {}
-    while nxt < len(fps):
-        group = list(range(nxt, min(nxt + max(1, files_per_sync), len(fps))))
-        states, cands, counts, n_frames = [], [], [], 1
-        for i in group:
-            a, p = mix(i)
-            stop = a.numel() - n - 1
-            if stop < 0:
-                raise ValueError(f"signal of {a.numel()} samples is shorter than a {length} s clip")
-            states.append(r.getstate())
-            cands.append(r.randint(0, stop))
-            c, n_frames, _, _ = gate_counts(a, p, [cands[-1]], n)
-            counts.append(c)
-        got = torch.cat(counts).tolist()                                  # the one synchronisation of this group
-        for j, i in enumerate(group):
+    dev = signals(0)[1].device
+    bank = torch.empty((len(fps), 2, 96, T), dtype=torch.float32, device=dev)
+    staged = torch.empty((chunk, 2, n), dtype=torch.float32, device=dev)
+    row_off = torch.arange(chunk, dtype=torch.int64, device=dev) * (2 * n)       # start of staging row k, for the gate
+    counts = torch.empty(chunk, dtype=torch.int32, device=dev)
+
+    def stage(first_row: int, rows):
+        """rows: [(others, drums, start)] -> staging rows first_row ...; returns the tensors that must outlive the launch."""
+        tab = torch.zeros((len(rows), row_len), dtype=torch.int64, pin_memory=True)
+        tn = tab.numpy()
+        for k, (others, drums, st) in enumerate(rows):
+            tn[k, 0] = len(others)
+            tn[k, 1] = st
+            tn[k, 2] = drums.data_ptr()
+            for q, o in enumerate(others):
+                tn[k, 3 + q] = o.data_ptr()
+        dtab = tab.to(dev, non_blocking=True)
+        with _ops.on_device(staged):
+            rc = L.zns_stage_crops_f32(dtab.data_ptr(), len(rows), MAX_OTHER, n, staged[first_row].data_ptr(),
+                                       _ops.stream_ptr(dev))
+        _lib.check(rc, "zns_stage_crops_f32")
+        return tab, dtab, rows
+
+    pos = 0                       # next file whose crop start is unknown
+    keep = []
+    while pos < len(fps):
+        base = pos - pos % chunk                                           # this chunk's first file = staging row 0
+        F = min(max(1, files_per_sync), len(fps) - pos, base + chunk - pos)
+        rows = []
+        state0 = r.getstate()                 # one snapshot per group (it is a 625-word tuple): a miss replays the draws before it
+        for i in range(pos, pos + F):
+            others, drums = signals(i)
+            rows.append((others, drums, r.randint(0, drums.numel() - n - 1)))
+        k0 = pos - base
+        keep.append(stage(k0, rows))
+        with _ops.on_device(staged):
+            rc = L.zns_rms_gate_f32(staged.data_ptr(), staged.data_ptr() + 4 * n, row_off[k0:].data_ptr(), F, n, None, None,
+                                    counts.data_ptr(), _ops.stream_ptr(dev))
+        _lib.check(rc, "zns_rms_gate_f32")
+        got = counts[:F].tolist()                                          # the one synchronisation of this group
+        keep.clear()
+        for j in range(F):
             if _first_pass(got[j], n_frames, lower_p, upper_p):
-                starts[i] = cands[j]
-                nxt = i + 1
+                pos += 1
                 continue
-            r.setstate(states[j])                                         # a miss: this file runs the reference's loop
-            a, p = mix(i)
-            starts[i] = select_clip(a, p, length, lower_p, upper_p, r)
-            nxt = i + 1
-            break                                                         # later files' draws start after this one's
-        # crop every file whose start is now known into the staging buffer; transform whole chunks
-        while done < nxt:
-            if staged is None:
-                a0 = mix(done)[0]
-                staged = torch.empty((min(chunk, len(fps)), 2, n), dtype=torch.float32, device=a0.device)
-                bank = torch.empty((len(fps), 2, 96, T), dtype=torch.float32, device=a0.device)
-            lo = done - done % staged.shape[0]                            # first row of the chunk being staged
-            k = done - lo
-            a, p = mixes.pop(done)
-            st = starts.pop(done)
-            staged[k, 0].copy_(a[st:st + n])
-            staged[k, 1].copy_(p[st:st + n])
-            done += 1
-            if k + 1 == staged.shape[0] or done == len(fps):
-                generate_XQT_batch(staged[:k + 1].reshape(2 * (k + 1), n), 16000, mode,
-                                   out=bank[lo:done].view(2 * (k + 1), 96, T))
+            # a miss: this file runs the reference's loop from its first draw; later files' draws start after its last
+            r.setstate(state0)
+            for q in range(j):
+                r.randint(0, rows[q][1].numel() - n - 1)
+            others, drums = rows[j][0], rows[j][1]
+            anchor, _ = mix_stems(all_stems[fps[pos].strip()])
+            st = select_clip(anchor, drums, length, lower_p, upper_p, r)
+            keep.append(stage(pos - base, [(others, drums, st)]))
+            pos += 1
+            break
+        if pos - base == chunk or pos == len(fps):                         # the chunk's rows are final: transform them
+            k = pos - base
+            generate_XQT_batch(staged[:k].reshape(2 * k, n), 16000, mode, out=bank[base:pos].view(2 * k, 96, T))
     return bank
