@@ -595,7 +595,7 @@ __device__ __forceinline__ void fb_run(const FbArgs& P, const FbRun r, int clip,
         pre = ti + 1 < r.ntile && tile + 1 < P.tiles && interior(t0 + 32);
         if (pre) load_tile(t0 + 32);                    // in flight while this tile is multiplied
         // same-wave LDS traffic is ordered: no barrier between the writes above and the reads below
-        fb_multiply<NFFT>(P.out, P.n_frames, hop, oct, clip, t0, lw, lane, a);
+        fb_multiply<NFFT>(P.out, P.n_frames, hop, oct, clip, t0, lw, lane, a);   // (compile-time staging strides measured: no gain here)
     }
 }
 
@@ -1175,12 +1175,12 @@ int zns_xqt_stages_f32(const float* wav, int n_clips, int n_samples, int sample_
             return launch_march(b, L, len, n_clips, n_samples, out, st);
         }
     }
-    // decimation pyramid: levels 1..7, grouped into chains (one launch each).  Default plan: the three big levels on
-    // their own (no recomputed halo where 7/8 of the taps are), the four small ones fused (their launches are
-    // latency-bound: 6.5 us each for a 32-clip batch).  ZNS_XQT_PLAN="n1,n2,.." overrides the grouping (tuning aid).
+    // decimation pyramid: levels 1..7, grouped into chains (one launch each).  Default plan: the two big levels on
+    // their own (no recomputed halo where 3/4 of the taps are), then chains of two and three (the small levels' launches
+    // are latency-bound: 6.5 us each for a 32-clip batch).  ZNS_XQT_PLAN="n1,n2,.." overrides the grouping (tuning aid).
     if (stages & 1) {
         // big batches: one launch per level (the fused tail recomputes halos and runs few blocks); small ones: fused tail
-        int plan[XQ_OCT] = {1, 1, 1, 4, 1, 1, 1}, nplan = 4;
+        int plan[XQ_OCT] = {1, 1, 2, 3, 1, 1, 1}, nplan = 4;     // tools/exp_xqt_plan_sweep.py: 87 us against 91 for {1,1,1,4} at 32 clips
         if (n_clips >= 256) { nplan = 7; for (int i = 0; i < 7; ++i) plan[i] = 1; }
         if (const char* e = getenv("ZNS_XQT_PLAN")) {
             nplan = 0;
