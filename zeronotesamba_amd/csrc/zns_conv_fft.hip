@@ -360,15 +360,47 @@ __global__ void __launch_bounds__(256) pack_freq_weights_kernel(Ptr2 w, float* _
     // G[f] = sum_s W[s] e^{+2 pi i f s / 64} = conj(DFT_64(W zero padded)[f]): one register FFT per thread (the first
     // version summed 32 x kw twiddle products through LDS: 1600 FMAs and 800 LDS reads per thread)
     float x[FN];
-    if (!transposed) {
-        const float* wr = w.p[br] + (((size_t)co * cin_c + ci) * kh + tap) * kw;                     // W[co][ci][tap][s]
+    // The kw taps of one (co, ci, row) are ONE contiguous run in the OIHW tensor (4-byte aligned only: kw is odd), and the
+    // runs of neighbouring lanes are far apart: read it with 16-byte loads (7 instead of 25 requests of 64 different
+    // lines each), then place / flip in registers.  The run may be read up to 3 floats past its end -- inside the tensor
+    // except for its very last run, where the tail is fetched element-wise.
+    struct __attribute__((packed, aligned(4))) U4 { float v[4]; };
+    float t[28];
+    {
+        const size_t run = !transposed ? (((size_t)co * cin_c + ci) * kh + tap) * kw
+                                       : (((size_t)ci * cout_c + co) * kh + (kh - 1 - tap)) * kw;
+        const float* wr = w.p[br] + run;
+        const bool last = run + 28 > (size_t)cout_c * cin_c * kh * kw;     // would run past the tensor
+        if (!last) {
 #pragma unroll
-        for (int s = 0; s < FN; ++s) x[s] = (s < 25 && s < kw) ? wr[s] : 0.f;
+            for (int q = 0; q < 7; ++q) {
+                if (4 * q < kw) {
+                    const U4 u = *reinterpret_cast<const U4*>(wr + 4 * q);
+                    t[4 * q] = u.v[0]; t[4 * q + 1] = u.v[1]; t[4 * q + 2] = u.v[2]; t[4 * q + 3] = u.v[3];
+                } else {
+                    t[4 * q] = t[4 * q + 1] = t[4 * q + 2] = t[4 * q + 3] = 0.f;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 28; ++s) t[s] = (s < kw) ? wr[s] : 0.f;
+        }
+    }
+    if (!transposed) {
+#pragma unroll
+        for (int s = 0; s < FN; ++s) x[s] = (s < 25 && s < kw) ? t[s] : 0.f;
     } else {
         // original tensor [cout_o = cin_c][cin_o = cout_c][kh][kw]; flipped in both kernel axes
-        const float* wr = w.p[br] + (((size_t)ci * cout_c + co) * kh + (kh - 1 - tap)) * kw;
 #pragma unroll
-        for (int s = 0; s < FN; ++s) x[s] = (s < 25 && s < kw) ? wr[kw - 1 - s] : 0.f;
+        for (int s = 0; s < FN; ++s) {
+            float v = 0.f;
+            if (s < 25) {
+#pragma unroll
+                for (int k = 13; k <= 25; k += 2)                           // kw is one of 13, 15, ... 25: a static index per case
+                    if (kw == k && s < k) v = t[k - 1 - s];
+            }
+            x[s] = v;
+        }
     }
     float sr[FF], si[FF];
     rfft64(x, sr, si);
