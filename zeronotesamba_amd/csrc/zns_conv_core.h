@@ -297,6 +297,13 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
 #pragma unroll
                 for (int k = 0; k < 16; ++k) acc[m][rt][ct][k] = 0.f;
 
+    // Frequency-domain launches (8 or 12 waves, 2-3 per SIMD): the last-dispatched wave of every SIMD loses instruction
+    // arbitration to its older partners in every stage (priority, then age); ONE static priority raise for that last
+    // third removes its start-of-stage penalty (dominant kernel 2.385 -> 2.345 ms, 0.845 -> 0.857 of peak; raising the
+    // OLDER third instead, or the same in the backward-weights kernels, measured nothing).
+    if constexpr (C::DILMAX > 0 && C::NW >= 8) {
+        if (wid >= C::NW - 4) __builtin_amdgcn_s_setprio(1);
+    }
     const bool type_a = !C::HET || wid < C::HET;       // HET: the last four waves own one channel tile x 3 column tiles
     const int het_m0 = wid - C::HET;
     const int pw_al = (pw + 3) & ~3;   // patch origin = tile origin - pw_al (16-byte aligned); reads skip pw_al - pw
