@@ -460,6 +460,11 @@ def test_two_streams_on_one_device_do_not_share_scratch():
     assert len(_ops._workspaces) >= n_ws + 2              # each side stream got its own scratch
     for (wa, wp), (ga, gp) in zip(want, got):
         assert torch.equal(wa, ga) and torch.equal(wp, gp)
+    _ops.release_workspaces(DEV)                          # grow-only buffers can be handed back
+    assert not [k for k in _ops._workspaces if k[0] == torch.device(DEV).index]
+    with torch.no_grad():
+        again = m(*xs[0])
+    assert torch.equal(again[0], want[0][0])
 
 
 def test_probe_is_single_owner():

@@ -83,6 +83,15 @@ def workspace(nbytes: int, device: torch.device, slot: int = 0) -> torch.Tensor:
     return ws
 
 
+def release_workspaces(device=None) -> None:
+    """Drop the scratch buffers (of `device`, or of every device): they are grow-only and one set exists per stream that
+    ever launched a kernel, so a process that cycles through many streams or shrinks its batch size can give the memory
+    back.  Safe at any time: a buffer still referenced by enqueued kernels stays alive in torch's stream-ordered allocator."""
+    idx = None if device is None else torch.device(device).index
+    for key in [k for k in _workspaces if idx is None or k[0] == idx]:
+        del _workspaces[key]
+
+
 def conv_workspace_bytes(nbr: int, B: int, T: int) -> int:
     """Largest per-layer workspace of one stack pass (split-K factors follow the CURRENT device's CU count)."""
     L = _lib.lib()
