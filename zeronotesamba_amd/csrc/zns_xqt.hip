@@ -485,15 +485,25 @@ __device__ __forceinline__ void fb_multiply(float* __restrict__ out, int n_frame
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[k] = 0.f;
     const float* __restrict__ bp = lw + j * (hopL + 1) + kk;
-    // operands are read 8 k-steps at a time (a scheduling fence keeps the compiler from hoisting all n_fft / 2 reads
-    // into registers at once: with the A operand and the prefetched tile resident that would spill)
+    // B operands are read BB k-steps at a time and ONE BATCH AHEAD: the reads of batch i + 1 are issued before the MFMAs of
+    // batch i, so the dependent MFMA chain (one every 64 cycles) does not wait for LDS (read-then-multiply per batch, or
+    // the compiler's own pairing through two registers, left ~40 idle cycles per two MFMAs).  The scheduling fences keep
+    // that order and keep the compiler from hoisting all n_fft / 2 reads at once (with the A operand and the prefetched
+    // tile resident that would spill).  Two batches of 4 = the 8 registers the un-pipelined form used.
+    constexpr int BB = 4;
+    float bv[2][BB];
 #pragma unroll
-    for (int s0 = 0; s0 < NFFT / 2; s0 += 8) {
-        float bv[8];
+    for (int u = 0; u < BB; ++u) bv[0][u] = bp[2 * u + ((2 * u) >> lg)];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) bv[u] = bp[2 * (s0 + u) + ((2 * (s0 + u)) >> lg)];
+    for (int s0 = 0; s0 < NFFT / 2; s0 += BB) {
+        const int cur = (s0 / BB) & 1;
+        if (s0 + BB < NFFT / 2) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s0 + u], bv[u], acc, 0, 0, 0);
+            for (int u = 0; u < BB; ++u) bv[cur ^ 1][u] = bp[2 * (s0 + BB + u) + ((2 * (s0 + BB + u)) >> lg)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < BB; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s0 + u], bv[cur][u], acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
     // ---- rows 2k / 2k+1 of one filter are neighbouring registers of one lane: |V|, log, coalesced along time
@@ -513,12 +523,18 @@ __device__ __forceinline__ void fb_multiply(float* __restrict__ out, int n_frame
     }
 }
 
-template <int NFFT>
+// LG >= 0: log2(min(hop, n_fft)) as a compile-time constant (the octaves of the VQT bank): the tile image's size and every
+// per-piece guard are then constants, the prefetch is straight-line code and the B operand reads are `base + immediate`.
+// LG < 0: taken from `hop` at run time (the CQT bank: 256 taps in every octave).
+template <int NFFT, int LG = -1>
 __device__ __forceinline__ void fb_run(const FbArgs& P, const FbRun r, int clip, float* __restrict__ lw, int lane) {
     const int oct = r.oct;
-    const int hop = P.L.hop[oct], len = P.L.len[oct];
-    const int hopL = hop < NFFT ? hop : NFFT;
-    const int lg = 31 - __builtin_clz(hopL);
+    const int hop_rt = P.L.hop[oct], len = P.L.len[oct];
+    constexpr int LGC = LG >= 0 ? LG : 0;
+    // hop itself is only a constant when it is below n_fft (segment layout); in the windows layout it stays run time
+    const int hop = (LG >= 0 && (1 << LGC) < NFFT) ? (1 << LGC) : hop_rt;
+    const int hopL = LG >= 0 ? (1 << LGC) : (hop < NFFT ? hop : NFFT);
+    const int lg = LG >= 0 ? LG : 31 - __builtin_clz(hopL);
     const float* __restrict__ y = P.L.y[oct] + (long long)clip * P.L.stride[oct];
     float a[NFFT / 2];
     const float* __restrict__ ga = P.fira + P.offa[oct] + lane;
@@ -531,7 +547,7 @@ __device__ __forceinline__ void fb_run(const FbArgs& P, const FbRun r, int clip,
     // and its registers are loaded while the PREVIOUS tile is being multiplied (one memory latency per run of tiles is
     // exposed, not one per tile); the two tiles at the ends of the signal are staged element by element.
     constexpr int NV = NFFT / 8;
-    const bool win = hop >= NFFT;
+    const bool win = LG >= 0 ? (1 << LGC) == NFFT : hop >= NFFT;
     const int nel = win ? 32 * NFFT : 31 * hop + NFFT;
     const bool vec_ok = (hop & 3) == 0 && P.L.vec[oct];
     auto dst = [&](int e) { return win ? (e / NFFT) * (NFFT + 1) + (e & (NFFT - 1)) : e + (e >> lg); };
@@ -585,17 +601,29 @@ __device__ __forceinline__ void fb_run(const FbArgs& P, const FbRun r, int clip,
     };
     const int first = r.tile0;
     if (first >= P.tiles) return;
-    bool pre = interior(first * 32);
-    if (pre) load_tile(first * 32);
+    // first tile of the run: staged synchronously
+    if (interior(first * 32)) { load_tile(first * 32); store_tile(); } else stage_edge(first * 32);
+    // ... and the A operand is KNOWN to have landed before the loop (consuming its registers puts the wait here, once).
+    // Its loads are older than every tile prefetch; left pending into the loop, the first MFMA of EVERY tile carried a
+    // vmcnt wait that also covered (part of) the prefetch just issued: the memory latency exposed per tile, the matrix
+    // pipe 43 % busy (round 2).
+#pragma unroll
+    for (int s0 = 0; s0 < NFFT / 2; s0 += 8)
+        asm volatile("" ::"v"(a[s0]), "v"(a[s0 + 1]), "v"(a[s0 + 2]), "v"(a[s0 + 3]), "v"(a[s0 + 4]), "v"(a[s0 + 5]),
+                     "v"(a[s0 + 6]), "v"(a[s0 + 7]));
     for (int ti = 0; ti < r.ntile; ++ti) {
         const int tile = first + ti;
         if (tile >= P.tiles) break;
         const int t0 = tile * 32;
-        if (pre) store_tile(); else stage_edge(t0);     // the previous tile's operand reads have all been consumed
-        pre = ti + 1 < r.ntile && tile + 1 < P.tiles && interior(t0 + 32);
-        if (pre) load_tile(t0 + 32);                    // in flight while this tile is multiplied
-        // same-wave LDS traffic is ordered: no barrier between the writes above and the reads below
-        fb_multiply<NFFT>(P.out, P.n_frames, hop, oct, clip, t0, lw, lane, a);   // (compile-time staging strides measured: no gain here)
+        // the NEXT tile: requested now, in flight while this tile is multiplied, written to LDS after the multiply -- the
+        // loaded values live inside one iteration (carried across the loop edge, two of the 64 registers were copied right
+        // behind the loads: another wait for the whole prefetch in front of the first MFMA)
+        const bool more = ti + 1 < r.ntile && tile + 1 < P.tiles;
+        const bool pre = more && interior(t0 + 32);
+        if (pre) load_tile(t0 + 32);
+        // same-wave LDS traffic is ordered: no barrier between staging writes and operand reads
+        fb_multiply<NFFT, LG>(P.out, P.n_frames, hop, oct, clip, t0, lw, lane, a);
+        if (pre) store_tile(); else if (more) stage_edge(t0 + 32);
     }
 }
 
@@ -611,13 +639,28 @@ __global__ void __launch_bounds__(256, MAXFFT <= 128 ? 2 : 1) xqt_filter_kernel(
     const int group = bid % P.blocks_per_clip; bid /= P.blocks_per_clip;
     const int clip = bid % P.n_clips;
     const FbRun r{P.order[bid / P.n_clips], (4 * group + wid) * P.tpw, P.tpw};
-    switch (P.L.n_fft[r.oct]) {
-        case 16: fb_run<16>(P, r, clip, lw, lane); break;
-        case 32: fb_run<32>(P, r, clip, lw, lane); break;
-        case 64: fb_run<64>(P, r, clip, lw, lane); break;
-        case 128: fb_run<128>(P, r, clip, lw, lane); break;
+    const int nf = P.L.n_fft[r.oct], hp = P.L.hop[r.oct];
+    const int key = nf * 16 + (31 - __builtin_clz(hp < nf ? hp : nf));       // (n_fft, log2 of the staging stride)
+    switch (key) {
+        // the VQT bank (octaves 0..7: n_fft 128,128,128,128,64,32,32,16; hop 256 >> octave)
+        case 128 * 16 + 7: fb_run<128, 7>(P, r, clip, lw, lane); break;
+        case 128 * 16 + 6: fb_run<128, 6>(P, r, clip, lw, lane); break;
+        case 128 * 16 + 5: fb_run<128, 5>(P, r, clip, lw, lane); break;
+        case 64 * 16 + 4: fb_run<64, 4>(P, r, clip, lw, lane); break;
+        case 32 * 16 + 3: fb_run<32, 3>(P, r, clip, lw, lane); break;
+        case 32 * 16 + 2: fb_run<32, 2>(P, r, clip, lw, lane); break;
+        case 16 * 16 + 1: fb_run<16, 1>(P, r, clip, lw, lane); break;
         default:
-            if constexpr (MAXFFT > 128) fb_run<256>(P, r, clip, lw, lane);
+            // anything else (the CQT bank) through the run-time form
+            switch (nf) {
+                case 16: fb_run<16>(P, r, clip, lw, lane); break;
+                case 32: fb_run<32>(P, r, clip, lw, lane); break;
+                case 64: fb_run<64>(P, r, clip, lw, lane); break;
+                case 128: fb_run<128>(P, r, clip, lw, lane); break;
+                default:
+                    if constexpr (MAXFFT > 128) fb_run<256>(P, r, clip, lw, lane);
+                    break;
+            }
             break;
     }
 }
