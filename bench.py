@@ -414,6 +414,8 @@ def measure_pipeline(dev) -> dict:
     res = _timed(lambda: trainer.step(x), steps, 3)
     out["epoch_path"] = {"frames": crop, "bank_clips": n_clips, "steps": steps, "ms_per_step": ep,
                          "resident_batch_ms_per_step": res, "vs_resident_batch": ep / res,
+                         "us_per_frame_pair": ep * 1e3 / (B * crop),
+                         "executed_frac_of_fp32_mfma_peak": exec_flop(crop, 2 * B) / (ep * 1e-3) / (FP32_MFMA_PEAK_TFLOPS * 1e12),
                          "audio_seconds_per_s": 1e3 / ep * B * crop * HOP / SR}
     del trainer, sb, bank, x
     torch.cuda.empty_cache()
