@@ -475,7 +475,7 @@ struct FbArgs {
 // the per-octave launch (fb_run) and the marching kernel, so both produce the same bits.
 // LG >= 0: log2(min(hop, n_fft)) known at compile time -- every B operand read is then `base + immediate`; LG < 0: taken
 // from `hop` at run time (the per-octave launch: one address per k-step, computed once per run of tiles).
-template <int NFFT, int LG = -1>
+template <int NFFT, int LG = -1, int BB = 4>
 __device__ __forceinline__ void fb_multiply(float* __restrict__ out, int n_frames, int hop, int oct, int clip, int t0,
                                             const float* __restrict__ lw, int lane, const float (&a)[NFFT / 2]) {
     const int hopL = LG >= 0 ? (1 << (LG >= 0 ? LG : 0)) : (hop < NFFT ? hop : NFFT);
@@ -490,8 +490,7 @@ __device__ __forceinline__ void fb_multiply(float* __restrict__ out, int n_frame
     // the compiler's own pairing through two registers, left ~40 idle cycles per two MFMAs).  The scheduling fences keep
     // that order and keep the compiler from hoisting all n_fft / 2 reads at once (with the A operand and the prefetched
     // tile resident that would spill).  Two batches of 4 = the 8 registers the un-pipelined form used.
-    constexpr int BB = 4;
-    float bv[2][BB];
+    float bv[2][BB];                // BB = 4 in the per-octave launch; the marching kernel (168 registers) takes 2
 #pragma unroll
     for (int u = 0; u < BB; ++u) bv[0][u] = bp[2 * u + ((2 * u) >> lg)];
 #pragma unroll
@@ -814,9 +813,9 @@ __device__ __forceinline__ void mq_fb_operand(const MqOct& O, int lane, float (&
 __device__ __forceinline__ void mq_fb_compute_heavy(float* __restrict__ out, int n_frames, const MqOct& O, int clip, int t0,
                                                     const float* __restrict__ lw, int lane, const float (&a)[64]) {
     switch (O.lgh) {
-        case 7: fb_multiply<128, 7>(out, n_frames, O.hop, O.oct, clip, t0, lw, lane, a); break;
-        case 6: fb_multiply<128, 6>(out, n_frames, O.hop, O.oct, clip, t0, lw, lane, a); break;
-        default: fb_multiply<128, 5>(out, n_frames, O.hop, O.oct, clip, t0, lw, lane, a); break;
+        case 7: fb_multiply<128, 7, 2>(out, n_frames, O.hop, O.oct, clip, t0, lw, lane, a); break;
+        case 6: fb_multiply<128, 6, 2>(out, n_frames, O.hop, O.oct, clip, t0, lw, lane, a); break;
+        default: fb_multiply<128, 5, 2>(out, n_frames, O.hop, O.oct, clip, t0, lw, lane, a); break;
     }
 }
 template <int NFFT, int LG>
@@ -824,7 +823,7 @@ __device__ __forceinline__ void mq_fb_compute(float* __restrict__ out, int n_fra
                                               const float* __restrict__ lw, int lane) {
     float a[NFFT / 2];
     mq_fb_operand<NFFT>(O, lane, a);
-    fb_multiply<NFFT, LG>(out, n_frames, O.hop, O.oct, clip, t0, lw, lane, a);
+    fb_multiply<NFFT, LG, 2>(out, n_frames, O.hop, O.oct, clip, t0, lw, lane, a);
 }
 __device__ __forceinline__ void mq_fb_compute_light(float* __restrict__ out, int n_frames, const MqOct& O, int clip, int t0,
                                                     const float* __restrict__ lw, int lane) {
@@ -1204,7 +1203,7 @@ int zns_xqt_stages_f32(const float* wav, int n_clips, int n_samples, int sample_
     // transform (same bits, tests/test_vqt.py) and moves fewer HBM bytes (8-11 GB against 13 GB per 4096 clips), but it is not faster: on gfx950 an fp32
     // MFMA and a vector instruction of the same SIMD do not execute together (tools/ubench_f64_mfma.hip: both = sum), so
     // there is no matrix-pipe time to hide under the float64 issue stream, and at its 2 pyramid waves per SIMD the taps run
-    // slower than in the 5-waves-per-SIMD chain launches (4096 clips: 6.3 ms against 6.0 ms).
+    // slower than in the 8-waves-per-SIMD chain launches (4096 clips: 6.25 ms against 5.65-6.0 ms).
     // CQT (256 taps in every octave) does not fit its register budget.
     if (stages == 3 && !(plan_flags & ZNS_XQT_SEPARATE)) {
         int max_fft = 0;
