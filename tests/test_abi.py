@@ -38,6 +38,45 @@ def test_host_only_entry_points():
     assert rc == _lib.ZNS_ERR_MODE and b"Mode can only be vqt or cqt!" in L.zns_last_error()
 
 
+def test_size_queries_survive_degenerate_arguments():
+    """Every *_bytes / *_frames query with an empty or negative extent answers (0 or the minimum) instead of dividing
+    by it: a zero batch once raised SIGFPE inside zns_conv2d_workspace_bytes.  In a child process, so that a fault is a
+    test failure and not the end of the test run."""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes as C, itertools, sys
+sys.path.insert(0, %r)
+from zeronotesamba_amd import _lib
+L = _lib.lib()
+good = [2, 16, 512, 128, 128, 9, 17, 32]
+lid = C.c_int(7)
+for pos in range(8):
+    for bad in (0, -1, -2147483648):
+        a = list(good); a[pos] = bad
+        assert L.zns_conv2d_workspace_bytes(*a) in (0, 256), (a,)
+        assert L.zns_conv2d_spectrum_bytes(*a) == 0, (a,)
+        assert L.zns_conv2d_dz_spectrum_bytes(*a) == 0, (a,)
+        for tr in (0, 1):
+            assert L.zns_conv2d_packed_bytes(*a, tr, C.byref(lid)) == 0 and lid.value == 0, (a,)
+# geometries no kernel instance exists for: a size, never a fault
+for cin, cout, kh, kw, H in itertools.product((1, 3, 64), (5, 64), (1, 2, 3), (1, 4, 11), (1, 7, 96)):
+    for B, T in ((1, 1), (3, 31), (16, 512)):
+        L.zns_conv2d_workspace_bytes(2, B, T, cin, cout, kh, kw, H)
+        L.zns_conv2d_spectrum_bytes(2, B, T, cin, cout, kh, kw, H)
+        L.zns_conv2d_dz_spectrum_bytes(2, B, T, cin, cout, kh, kw, H)
+        L.zns_conv2d_packed_bytes(2, B, T, cin, cout, kh, kw, H, 0, None)
+for v in (0, -1, -2147483648):
+    assert L.zns_ntxent_workspace_bytes(v) == 256
+    assert L.zns_xqt_workspace_bytes(v, 160000, 0) == 256 and L.zns_xqt_workspace_bytes(4, v, 0) == 256
+    assert L.zns_xqt_frames(v) in (0, 1) and L.zns_rms_frames(v) in (0, 1)
+assert L.zns_xqt_workspace_bytes(1, 1, 0) >= 4 and L.zns_xqt_workspace_bytes(1, 2147483647, 1) > 2**32
+print("ok")
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from zeronotesamba_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)

@@ -246,3 +246,15 @@ def test_unsupported_and_bad_arguments_fail_loudly():
     rc = L.zns_conv2d_fwd_f32(1, 0, 16, 1, 64, 3, 11, 96, 1, x.data_ptr(), _ops._pp(w), _ops._pp(b), y.data_ptr(),
                               None, 0.0, 0, 0, None, None, ws.data_ptr(), ws.numel(), _ops.stream_ptr())
     assert rc == -1 and b"empty" in L.zns_last_error()
+
+
+def test_compute_entry_points_refuse_degenerate_extents():
+    """Every compute entry point, each integer argument replaced by 0 and by -1: extents are refused with an error
+    code, flags are served, nothing faults (tests/abi_degenerate_worker.py, in a child process so that a fault fails
+    the test instead of ending the run)."""
+    import os
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "abi_degenerate_worker.py")
+    r = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout[-800:], r.stderr[-3000:])

@@ -27,7 +27,8 @@ static bool is_cv1(const ConvArgs& a) { return a.cin == 1 && a.cout == 64 && a.k
 static int check_conv(const ConvArgs& a, const char* who) {
     ZNS_CHECK_ARG(a.nbr >= 1 && a.nbr <= 2, "%s: nbr=%d not in {1,2}", who, a.nbr);
     ZNS_CHECK_ARG(a.B >= 1 && a.T >= 1 && a.H >= 1, "%s: empty batch/time axis (B=%d T=%d H=%d)", who, a.B, a.T, a.H);
-    ZNS_CHECK_ARG(a.cin >= 1 && a.cout >= 1 && (a.kh & 1) && (a.kw & 1), "%s: bad conv geometry", who);
+    ZNS_CHECK_ARG(a.cin >= 1 && a.cout >= 1 && a.kh >= 1 && a.kw >= 1 && (a.kh & 1) && (a.kw & 1),
+                  "%s: bad conv geometry (cin=%d cout=%d k=%dx%d: odd kernels only)", who, a.cin, a.cout, a.kh, a.kw);
     ZNS_CHECK_ARG(a.pool >= 1 && a.H % a.pool == 0, "%s: pool=%d does not divide H=%d", who, a.pool, a.H);
     return ZNS_OK;
 }
@@ -66,7 +67,14 @@ int zns_probe_arm(int kind, int cin, int cout, int kh, void* const* ev_start, vo
 }
 int zns_probe_count(void) { return g_probe.count; }
 
+// the size queries take the same arguments as the calls they serve and must survive what those calls refuse (an empty
+// batch or time axis would otherwise reach the tile pickers' divisions)
+static bool degenerate(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H) {
+    return nbr < 1 || B < 1 || T < 1 || cin < 1 || cout < 1 || kh < 1 || kw < 1 || H < 1;
+}
+
 size_t zns_conv2d_workspace_bytes(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H) {
+    if (degenerate(nbr, B, T, cin, cout, kh, kw, H)) return 256;
     ConvArgs a{nbr, B, T, cin, cout, kh, kw, H, 1};
     size_t n = 256;
     if (is_cv1(a)) n = cv1_workspace_bytes(a);
@@ -76,11 +84,13 @@ size_t zns_conv2d_workspace_bytes(int nbr, int B, int T, int cin, int cout, int 
 }
 
 size_t zns_conv2d_spectrum_bytes(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H) {
+    if (degenerate(nbr, B, T, cin, cout, kh, kw, H)) return 0;
     ConvArgs a{nbr, B, T, cin, cout, kh, kw, H, 1};
     return (g_impl == ZNS_IMPL_AUTO && fft_wgrad_supported(a)) ? fft_spectrum_bytes(a) : 0;
 }
 
 size_t zns_conv2d_dz_spectrum_bytes(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H) {
+    if (degenerate(nbr, B, T, cin, cout, kh, kw, H)) return 0;
     ConvArgs a{nbr, B, T, cin, cout, kh, kw, H, 1};
     return (g_impl == ZNS_IMPL_AUTO && fft_wgrad_supported(a)) ? fft_dz_spectrum_bytes(a) : 0;
 }
@@ -96,6 +106,10 @@ static int conv_family(const ConvArgs& a, bool forward) {
 
 size_t zns_conv2d_packed_bytes(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, int transposed,
                                int* layout_id) {
+    if (degenerate(nbr, B, T, cin, cout, kh, kw, H)) {
+        if (layout_id) *layout_id = 0;
+        return 0;
+    }
     ConvArgs a{nbr, B, T, cin, cout, kh, kw, H, 1};
     const int fam = conv_family(a, !transposed);
     int id = 0;
