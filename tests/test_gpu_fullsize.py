@@ -305,3 +305,36 @@ def test_finetune_step_full_size_against_the_cpu_oracle(red):
         assert 0.5 * lr < float(dd.abs().max()) <= 1.1 * lr, k          # fp32 rounding of p - step: one ulp of p
     print("  Adam update: %d of %d elements differ by more than lr/10" % (n_bad, n_all))
     assert n_bad <= 1e-3 * n_all
+
+
+@pytest.mark.parametrize("B_big,T", [(80, 313), (48, 512)])
+def test_a_large_batch_equals_its_chunks_of_sixteen(B_big, T):
+    """Batch sizes beyond BASELINE's 16 (spectra of several GiB: 64-bit offsets, descriptors rebuilt per sample): with
+    dropout off a clip's activations do not depend on its batch, so the embeddings must be bit for bit those of the
+    same clips in chunks of 16, and the parameter gradients the sum over the chunks up to fp32 reassociation
+    (tools/diag_large.py runs the same check up to 400 clips per branch)."""
+    from zeronotesamba_amd import _ops
+    model = build()
+    x = synth(B_big, T, 4)
+    P = _ops.StackParams.from_flat(model.anchor.stack_params() + model.postve.stack_params(), 2)
+    demb_all = torch.randn((2 * B_big, T), generator=torch.Generator().manual_seed(9)).to(DEV)
+
+    def fb(xx, B, demb):
+        with torch.no_grad():
+            emb, acts, argm = _ops.stack_forward(xx, P, B, 0.0, 0, save=True)
+            grads = [torch.zeros_like(p) for p in P.flat()]
+            _ops.stack_backward(xx, P, B, acts, argm, emb, demb.contiguous(), None, 1.0, _ops.StackParams.from_flat(grads, 2))
+        torch.cuda.synchronize()
+        return emb, grads
+
+    e_big, g_big = fb(x, B_big, demb_all)
+    g_sum, ea, ep = None, [], []
+    for i in range(0, B_big, 16):
+        xc = torch.cat([x[i:i + 16], x[B_big + i:B_big + i + 16]]).contiguous()
+        dc = torch.cat([demb_all[i:i + 16], demb_all[B_big + i:B_big + i + 16]])
+        e, g = fb(xc, 16, dc)
+        ea.append(e[:16]); ep.append(e[16:])
+        g_sum = g if g_sum is None else [a + b for a, b in zip(g_sum, g)]
+    assert torch.equal(e_big, torch.cat(ea + ep))
+    for a, b in zip(g_big, g_sum):
+        assert ((a - b).norm() / b.norm().clamp_min(1e-30)).item() < 1e-4

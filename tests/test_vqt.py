@@ -235,6 +235,26 @@ def test_generate_xqt_launch_plans_agree_bitwise():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["vqt", "cqt"])
+def test_generate_xqt_is_local_a_long_clip_equals_its_excerpt(mode):
+    """Size-independent property for clips far beyond what the CPU oracle is run on (100 s; the fine-tune clips of config 4
+    are 30 s): every stage is a finite FIR, and the decimations keep their phase when an excerpt starts on a multiple of
+    2^7 * hop samples -- so the interior frames of a long clip are, bit for bit, the frames of an excerpt (which IS
+    checked against the oracle above), whatever block / tile of the long launch computed them."""
+    from zeronotesamba_amd.processing.input_rep import generate_XQT_batch
+    g = torch.Generator().manual_seed(99)
+    n_long, f0, f1, margin = 1_600_000, 1024, 2048, 256          # frames; 1024 = a multiple of 128 decimated samples too
+    y = (0.1 * torch.randn(2, n_long, generator=g)).cuda()
+    long = generate_XQT_batch(y, 16000, mode)
+    assert tuple(long.shape) == (2, 96, 1 + n_long // 256)
+    ex = generate_XQT_batch(y[:, 256 * f0:256 * f1].contiguous(), 16000, mode)
+    assert torch.equal(long[:, :, f0 + margin:f1 - margin], ex[:, :, margin:(f1 - f0) - margin])
+    # and the excerpt against the oracle (one clip)
+    ref = vqt_ref.generate_XQT(y[1, 256 * f0:256 * f1].cpu().numpy(), 16000, mode)
+    assert lin_err(ex[1].cpu().numpy(), ref) < 1e-5
+
+
+@pytest.mark.gpu
 def test_generate_xqt_linearity_at_full_size():
     """Size-independent property at BASELINE config 2 size: 32 clips x 160 000 samples."""
     from zeronotesamba_amd.processing.input_rep import generate_XQT_batch

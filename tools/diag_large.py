@@ -2,7 +2,7 @@
 chunks of 16 (dropout off, so a clip's activations do not depend on its batch) -- embeddings must be bitwise equal,
 parameter gradients equal the sum over chunks up to fp32 reassociation.  Looks for 32-bit index / 4-GiB descriptor
 overflows at sizes the 288 GB of an MI355X invite.  Also generate_XQT over more clips than one 4-GiB buffer holds.
-usage: python3 tools/diag_large.py [B_big ...] [T=512] [xqt=n_clips ...] [n=160000]   (default 64 128, xqt=8192 xqt=12288)"""
+usage: python3 tools/diag_large.py [B_big ...] [T=512] [xqt=n_clips ...] [n=160000] [chunk=4096]   (default 64 128, xqt=8192 xqt=12288)"""
 import os
 import sys
 
@@ -82,17 +82,18 @@ def xqt(n_clips, n=160000, chunk=4096):
 
 
 if __name__ == "__main__":
-    sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [64, 128]
+    sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or ([] if len(sys.argv) > 1 else [64, 128])
     T = next((int(a[2:]) for a in sys.argv[1:] if a.startswith("T=")), 512)
     clips = [int(a[4:]) for a in sys.argv[1:] if a.startswith("xqt=")] or [8192, 12288]
     n_samples = next((int(a[2:]) for a in sys.argv[1:] if a.startswith("n=")), 160000)
+    xchunk = next((int(a[6:]) for a in sys.argv[1:] if a.startswith("chunk=")), 4096)
     ok = True
     for B in sizes:
         ok = cnn(B, T) and ok
         ok = cnn_grads(B, T) and ok
         torch.cuda.empty_cache()
     for n in clips:
-        ok = xqt(n, n_samples) and ok
+        ok = xqt(n, n_samples, xchunk) and ok
         torch.cuda.empty_cache()
     print("ALL OK" if ok else "MISMATCH")
     sys.exit(0 if ok else 1)
