@@ -35,6 +35,11 @@ __device__ __forceinline__ void blds4(__amdgpu_buffer_rsrc_t rs, unsigned voff, 
 __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rs, unsigned voff, float* lds_dst) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)lds_dst, 16, (int)voff, 0, 0, 0);
 }
+// the same with the LDS destination as a byte address in a scalar register (a running value the caller steps)
+__device__ __forceinline__ unsigned lds_addr(const float* p) { return (unsigned)(size_t)(lds_void_t*)p; }
+__device__ __forceinline__ void blds4a(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned lds_byte) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(size_t)lds_byte, 4, (int)voff, 0, 0, 0);
+}
 
 // MFMA 32x32 accumulator: lane&31 = column, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 __device__ __forceinline__ int acc_row(int reg, int lane_h) { return (reg & 3) + 8 * (reg >> 2) + 4 * lane_h; }
@@ -519,8 +524,8 @@ struct WgCfg {
     static constexpr int PRW = RSPAN, PCW = CW + (KW - 1) * (DILMAX ? DILMAX : 1);
     static constexpr int PS = (PRW * PCW) | 1;               // odd plane stride: lanes (= channels) hit distinct banks
     static constexpr int ZBUF = COB * CW;                    // dZ tile [COB][CW], 16-byte chunks XOR-swizzled by the key above
-    static constexpr int XBUF = ((CIB * PS + 63) / 64) * 64;
-    static constexpr int NXI = (XBUF / 64 + NW - 1) / NW;    // X-patch DMA instructions per wave
+    static constexpr int XBUF = ((CIB * PS + 64 * NW - 1) / (64 * NW)) * (64 * NW);   // whole pieces for every wave
+    static constexpr int NXI = XBUF / 64 / NW;               // X-patch DMA instructions per wave
     static constexpr int NZI = (COB / RPI + NW - 1) / NW;    // dZ-tile DMA instructions per wave (16-byte pieces)
     static constexpr int LDS_BYTES = 2 * (ZBUF + XBUF) * 4;
     static constexpr int WPE = (NW == 4 && 2 * LDS_BYTES <= 160 * 1024) ? 2 : 1;   // 4-wave workgroups: two per CU
@@ -551,7 +556,7 @@ struct WgArgs {
 template <class C>
 __device__ __forceinline__ void wg_load_tile(const WgArgs& A, int br, int cob, int cit, int r0, int tile, float* zb,
                                              float* xb, int wid, int lane, const unsigned (&xvoff)[C::NXI],
-                                             const int (&xrc)[C::NXI], const unsigned (&zvoff)[C::NZI], int pcw, int nxq) {
+                                             const int (&xrc)[C::NXI], const unsigned (&zvoff)[C::NZI], int pcw) {
     const int T = A.T;
     const int cbk = tile % A.ncb;
     const int h0 = (tile / A.ncb) % C::H;
@@ -583,20 +588,23 @@ __device__ __forceinline__ void wg_load_tile(const WgArgs& A, int br, int cob, i
     const __amdgpu_buffer_rsrc_t rx =
         buf_rsrc(xbase, (unsigned)((((size_t)(C::CIB - 1) * C::H + C::PRW - 1) * T + pcw) * sizeof(float)));
     if (interior) {
+        // the lean path (28 of 30 tiles): per piece one M0 update (tile base + constant) and the DMA instruction --
+        // nothing on the vector pipe (which the partner workgroup's wave keeps full of MFMAs: every vector instruction
+        // issued here waits for a gap between them), no branches, no loop-invariant per-piece constants (27 LDS
+        // addresses + 27 `piece < pieces needed at this tap spacing` masks used to sit in scalar registers, half of them
+        // spilled to VGPR lanes and fetched back with v_readlane_b32, a vector-pipe instruction per piece).  Pieces past
+        // the patch of this tap spacing carry out-of-range offsets and move zeros into the unused tail of the buffer.
+        unsigned dst = lds_addr(xb) + wid * 256;
+        asm volatile("" : "+s"(dst));                  // opaque per tile: the piece addresses are not loop invariant
 #pragma unroll
-        for (int i = 0; i < C::NXI; ++i) {
-            const int q = wid + i * C::NW;
-            if (q < nxq) blds4(rx, xvoff[i], xb + q * 64);
-        }
+        for (int i = 0; i < C::NXI; ++i) blds4a(rx, xvoff[i], dst + i * C::NW * 256);
     } else {
 #pragma unroll
         for (int i = 0; i < C::NXI; ++i) {
             const int q = wid + i * C::NW;
-            if (q < nxq) {
-                const int hh = hbase + (xrc[i] >> 16), ww = wbase + (xrc[i] & 0xffff);
-                const bool ok = (unsigned)hh < (unsigned)C::H && (unsigned)ww < (unsigned)T;
-                blds4(rx, ok ? xvoff[i] : BUF_OOB, xb + q * 64);
-            }
+            const int hh = hbase + (xrc[i] >> 16), ww = wbase + (xrc[i] & 0xffff);
+            const bool ok = (unsigned)hh < (unsigned)C::H && (unsigned)ww < (unsigned)T;
+            blds4(rx, ok ? xvoff[i] : BUF_OOB, xb + q * 64);
         }
     }
 }
@@ -637,7 +645,6 @@ __global__ void __launch_bounds__(C::NT, C::WPE) wgrad_core(WgArgs A) {
     // columns that are read get staged (the LDS buffer is sized for DILMAX)
     const int pcw = C::DILMAX ? C::CW + (C::KW - 1) * A.dil : C::PCW;
     const int ps = C::DILMAX ? ((C::PRW * pcw) | 1) : C::PS;
-    const int nxq = C::DILMAX ? (C::CIB * ps + 63) / 64 : C::XBUF / 64;
     // per-lane source byte offsets of this wave's DMA instructions, relative to the tile origin (tile independent)
     unsigned xvoff[C::NXI], zvoff[C::NZI];
     int xrc[C::NXI];
@@ -674,13 +681,13 @@ __global__ void __launch_bounds__(C::NT, C::WPE) wgrad_core(WgArgs A) {
     }
 
     if (t_begin < t_end)
-        wg_load_tile<C>(A, br, cob, cit, r0, t_begin, zbuf(0), xbuf(0), wid, lane, xvoff, xrc, zvoff, pcw, nxq);
+        wg_load_tile<C>(A, br, cob, cit, r0, t_begin, zbuf(0), xbuf(0), wid, lane, xvoff, xrc, zvoff, pcw);
     int cur = 0;
     for (int tile = t_begin; tile < t_end; ++tile, cur ^= 1) {
         wait_vm0();
         __syncthreads();
         if (tile + 1 < t_end)
-            wg_load_tile<C>(A, br, cob, cit, r0, tile + 1, zbuf(cur ^ 1), xbuf(cur ^ 1), wid, lane, xvoff, xrc, zvoff, pcw, nxq);
+            wg_load_tile<C>(A, br, cob, cit, r0, tile + 1, zbuf(cur ^ 1), xbuf(cur ^ 1), wid, lane, xvoff, xrc, zvoff, pcw);
         const float* __restrict__ zp = zbuf(cur) + zrowbase;
         const float* __restrict__ xp = xbuf(cur);
 #pragma unroll
