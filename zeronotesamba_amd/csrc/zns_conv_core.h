@@ -37,6 +37,9 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rs, unsigned voff,
 }
 // the same with the LDS destination as a byte address in a scalar register (a running value the caller steps)
 __device__ __forceinline__ unsigned lds_addr(const float* p) { return (unsigned)(size_t)(lds_void_t*)p; }
+__device__ __forceinline__ float lds_ld(unsigned lds_byte) {
+    return *(const __attribute__((address_space(3))) float*)(size_t)lds_byte;
+}
 __device__ __forceinline__ void blds4a(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned lds_byte) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(size_t)lds_byte, 4, (int)voff, 0, 0, 0);
 }
@@ -689,7 +692,15 @@ __global__ void __launch_bounds__(C::NT, C::WPE) wgrad_core(WgArgs A) {
         if (tile + 1 < t_end)
             wg_load_tile<C>(A, br, cob, cit, r0, tile + 1, zbuf(cur ^ 1), xbuf(cur ^ 1), wid, lane, xvoff, xrc, zvoff, pcw);
         const float* __restrict__ zp = zbuf(cur) + zrowbase;
-        const float* __restrict__ xp = xbuf(cur);
+        // B operand: one LDS byte address per shift and tile (opaque, so that it IS the base register of the reads); the
+        // k position is then the instruction's immediate offset.  Left to itself the compiler bases every read on one
+        // per-tile register plus a constant beyond the immediate range: a v_add per read, on the pipe the MFMAs need.
+        unsigned xa[C::NS];
+#pragma unroll
+        for (int s = 0; s < C::NS; ++s) {
+            xa[s] = lds_addr(xbuf(cur)) + xoff[s] * 4;
+            asm volatile("" : "+v"(xa[s]));
+        }
 #pragma unroll
         for (int g = 0; g < C::CW / 8; ++g) {
             f32x4 a4[C::MT];
@@ -700,7 +711,7 @@ __global__ void __launch_bounds__(C::NT, C::WPE) wgrad_core(WgArgs A) {
             for (int s4 = 0; s4 < 4; ++s4) {
                 float b[C::NS];
 #pragma unroll
-                for (int s = 0; s < C::NS; ++s) b[s] = xp[xoff[s] + 8 * g + s4];
+                for (int s = 0; s < C::NS; ++s) b[s] = lds_ld(xa[s] + (8 * g + s4) * 4);
 #pragma unroll
                 for (int m = 0; m < C::MT; ++m)
 #pragma unroll
