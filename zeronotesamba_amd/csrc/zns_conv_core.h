@@ -602,12 +602,16 @@ __device__ __forceinline__ void wg_load_tile(const WgArgs& A, int br, int cob, i
 #pragma unroll
         for (int i = 0; i < C::NXI; ++i) blds4a(rx, xvoff[i], dst + i * C::NW * 256);
     } else {
+        // border tiles (2 of 30): the in-image test per piece.  Tile origin and LDS base opaque, so that nothing of this
+        // rare path is computed ahead of the K loop and kept in (spilled) scalar registers through the common one.
+        int hb = hbase, wb = wbase;
+        unsigned dst = lds_addr(xb) + wid * 256;
+        asm volatile("" : "+s"(hb), "+s"(wb), "+s"(dst));
 #pragma unroll
         for (int i = 0; i < C::NXI; ++i) {
-            const int q = wid + i * C::NW;
-            const int hh = hbase + (xrc[i] >> 16), ww = wbase + (xrc[i] & 0xffff);
+            const int hh = hb + (xrc[i] >> 16), ww = wb + (xrc[i] & 0xffff);
             const bool ok = (unsigned)hh < (unsigned)C::H && (unsigned)ww < (unsigned)T;
-            blds4(rx, ok ? xvoff[i] : BUF_OOB, xb + q * 64);
+            blds4a(rx, ok ? xvoff[i] : BUF_OOB, dst + i * C::NW * 256);
         }
     }
 }
