@@ -616,6 +616,10 @@ __device__ __forceinline__ void wg_load_tile(const WgArgs& A, int br, int cob, i
     }
 }
 
+// pixel group of a K-tile before which wave group `grp` issues the next tile's DMA pieces: group 0 at the start, the last
+// one no later than three quarters in (its pieces need the rest of the tile to land)
+constexpr int wg_stagger_at(int grp, int gsteps) { return grp == 0 ? 0 : grp == 1 ? gsteps / 2 : (3 * gsteps) / 4; }
+
 template <class C>
 __global__ void __launch_bounds__(C::NT, C::WPE) wgrad_core(WgArgs A) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -690,11 +694,20 @@ __global__ void __launch_bounds__(C::NT, C::WPE) wgrad_core(WgArgs A) {
     if (t_begin < t_end)
         wg_load_tile<C>(A, br, cob, cit, r0, t_begin, zbuf(0), xbuf(0), wid, lane, xvoff, xrc, zvoff, pcw);
     int cur = 0;
+    // One workgroup per CU (8 or 12 waves, 2-3 per SIMD): if every wave issued its share of the next tile's DMA pieces
+    // right after the barrier, the matrix pipes would idle for that long in every tile.  The waves of a SIMD take turns
+    // instead: group `wid / 4` issues its pieces after STAG_AT[group] of the tile's CW / 8 pixel groups, while its SIMD
+    // partners multiply.  (Two 4-wave workgroups per CU: the partner workgroup plays that role.)
+    constexpr int NG = C::NW >= 8 ? C::NW / 4 : 1;
+    constexpr int GSTEPS = C::CW / 8;
+    const int grp = NG > 1 ? wid / 4 : 0;
     for (int tile = t_begin; tile < t_end; ++tile, cur ^= 1) {
         wait_vm0();
         __syncthreads();
-        if (tile + 1 < t_end)
-            wg_load_tile<C>(A, br, cob, cit, r0, tile + 1, zbuf(cur ^ 1), xbuf(cur ^ 1), wid, lane, xvoff, xrc, zvoff, pcw);
+        if constexpr (NG == 1) {
+            if (tile + 1 < t_end)
+                wg_load_tile<C>(A, br, cob, cit, r0, tile + 1, zbuf(cur ^ 1), xbuf(cur ^ 1), wid, lane, xvoff, xrc, zvoff, pcw);
+        }
         const float* __restrict__ zp = zbuf(cur) + zrowbase;
         // B operand: one LDS byte address per shift and tile (opaque, so that it IS the base register of the reads); the
         // k position is then the instruction's immediate offset.  Left to itself the compiler bases every read on one
@@ -706,7 +719,14 @@ __global__ void __launch_bounds__(C::NT, C::WPE) wgrad_core(WgArgs A) {
             asm volatile("" : "+v"(xa[s]));
         }
 #pragma unroll
-        for (int g = 0; g < C::CW / 8; ++g) {
+        for (int g = 0; g < GSTEPS; ++g) {
+            if constexpr (NG > 1) {
+                bool mine = false;
+#pragma unroll
+                for (int q = 0; q < NG; ++q) mine = mine || (g == wg_stagger_at(q, GSTEPS) && grp == q);
+                if (mine && tile + 1 < t_end)
+                    wg_load_tile<C>(A, br, cob, cit, r0, tile + 1, zbuf(cur ^ 1), xbuf(cur ^ 1), wid, lane, xvoff, xrc, zvoff, pcw);
+            }
             f32x4 a4[C::MT];
             const int chunk = (2 * g) ^ zswz;
 #pragma unroll
