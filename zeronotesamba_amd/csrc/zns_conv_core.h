@@ -37,6 +37,9 @@ __device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t rs, unsigned voff,
 }
 // the same with the LDS destination as a byte address in a scalar register (a running value the caller steps)
 __device__ __forceinline__ unsigned lds_addr(const float* p) { return (unsigned)(size_t)(lds_void_t*)p; }
+__device__ __forceinline__ void blds16a(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, unsigned lds_byte) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(size_t)lds_byte, 16, (int)voff, (int)soff, 0, 0);
+}
 __device__ __forceinline__ float lds_ld(unsigned lds_byte) {
     return *(const __attribute__((address_space(3))) float*)(size_t)lds_byte;
 }
@@ -130,12 +133,15 @@ struct CoreArgs {
 };
 
 // Input patch [CK][PR][PCW] (+pad) of the workgroup's tile.  The tile is fixed for the whole kernel, so each wave
-// computes the per-lane source offsets of ITS DMA instructions once (patch_offsets: -1 = outside the image or the
-// padding -> zero page); staging a ci-chunk is then one add + select per instruction.
+// computes the per-lane source BYTE offsets of ITS DMA instructions once (patch_offsets: BUF_OOB = outside the image or
+// the padding -> the hardware range check moves zeros); staging a ci-chunk is then a buffer descriptor rebuilt from
+// scalars (base = the chunk's first channel) and one DMA instruction per piece -- nothing on the vector pipe, which in
+// the short-stage layouts (cv5 / cv6: 20 MFMAs per wave and stage) paid 14 address / select instructions per stage for
+// the per-lane 64-bit pointers and zero-page selects this replaced.
 template <class C>
 struct PatchPlan {
     static constexpr int NPI = (C::PATCH / 64 + C::NW - 1) / C::NW;   // 4-byte pieces per wave (16-byte mode uses a quarter)
-    int rel[NPI];
+    unsigned voff[NPI];
     bool wide;                                                         // 16-byte DMA pieces (wave-uniform)
 };
 
@@ -154,7 +160,7 @@ __device__ __forceinline__ void patch_offsets(PatchPlan<C>& pl, const float* xn,
         const int hh = h0 - C::PH + row, ww = w0 - pw_al + col;
         // T % 4 == 0 and a 4-aligned origin: a 16-byte piece is entirely inside or entirely outside the image
         const bool ok = (L < C::CK * C::PS) && (row < C::PR) && (col < live_cols) && hh >= 0 && hh < C::H && ww >= 0 && ww < T;
-        pl.rel[i] = ok ? (ci * C::H + hh) * T + ww : -1;
+        pl.voff[i] = ok ? (unsigned)(((ci * C::H + hh) * T + ww) * 4) : BUF_OOB;
     }
 }
 
@@ -162,25 +168,32 @@ template <class C>
 __device__ __forceinline__ void load_patch(const PatchPlan<C>& pl, const float* xn, int cc, int T, float* lds_patch,
                                            int wid) {
     const float* base = xn + (size_t)cc * C::CK * C::H * T;
+    const __amdgpu_buffer_rsrc_t rs = buf_rsrc(base, (unsigned)((size_t)C::CK * C::H * T * sizeof(float)));
     if (pl.wide) {
+        const unsigned dst = lds_addr(lds_patch) + wid * 1024;
 #pragma unroll
         for (int i = 0; i < (PatchPlan<C>::NPI + 3) / 4; ++i) {
             const int q = wid + i * C::NW;
-            if (q < C::PATCH / 256) glds16(pl.rel[i] >= 0 ? base + pl.rel[i] : g_zero_page, lds_patch + q * 256);
+            if (q < C::PATCH / 256) blds16a(rs, pl.voff[i], 0, dst + i * C::NW * 1024);
         }
     } else {
+        const unsigned dst = lds_addr(lds_patch) + wid * 256;
 #pragma unroll
         for (int i = 0; i < PatchPlan<C>::NPI; ++i) {
             const int q = wid + i * C::NW;
-            if (q < C::PATCH / 64) glds4(pl.rel[i] >= 0 ? base + pl.rel[i] : g_zero_page, lds_patch + q * 64);
+            if (q < C::PATCH / 64) blds4a(rs, pl.voff[i], dst + i * C::NW * 256);
         }
     }
 }
 
+// one weight slab (SLAB floats, contiguous thanks to the packing) in 1-KiB pieces: descriptor base = the slab, the piece
+// number goes into the scalar offset, the lane's 16 bytes into ONE constant vector offset
 template <class C>
 __device__ __forceinline__ void load_slab(const float* wslab, float* lds_slab, int wid, int lane) {
     constexpr int NI = C::SLAB / 256;
-    for (int q = wid; q < NI; q += C::NW) glds16(wslab + q * 256 + lane * 4, lds_slab + q * 256);
+    const __amdgpu_buffer_rsrc_t rs = buf_rsrc(wslab, (unsigned)(C::SLAB * sizeof(float)));
+    const unsigned dst = lds_addr(lds_slab);
+    for (int q = wid; q < NI; q += C::NW) blds16a(rs, (unsigned)lane * 16u, (unsigned)q * 1024u, dst + q * 1024);
 }
 
 // Epilogue helper: one 32x32 accumulator tile -> global rows of `ld` floats, through a per-wave LDS tile so that every
