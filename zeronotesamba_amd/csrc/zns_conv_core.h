@@ -2,6 +2,7 @@
 // backward-weights) shared by the direct path (zns_conv_mfma.hip) and the frequency-domain path
 // (zns_conv_fft.hip).  See zns_conv_mfma.hip for the design notes.
 #pragma once
+#include <type_traits>
 #include "zns_common.h"
 #include "zns_kernels.h"
 
@@ -215,52 +216,66 @@ __device__ __forceinline__ void store_tile_t(float* tb, const f32x16& acc, float
     }
 }
 
-template <class C>
-__device__ __forceinline__ void compute_stage(const float* __restrict__ pa, const float* __restrict__ pb,
-                                              f32x16 (&acc)[C::MT][C::RT][C::CT], int dil = 1) {
+// One K stage.  Operands are read through LDS BYTE ADDRESSES held in registers for the whole kernel: `a_addr` = this
+// wave's A base in the stage's slab buffer, `tap[s]` = its B base for kernel column s in patch buffer 0 (the tap spacing
+// is a run-time value in the frequency-domain use, so every tap needs its own base); everything else -- channel pair,
+// row / column tile, and with BOFF the patch buffer's parity -- is the read instruction's immediate offset.  With the
+// bases recomputed per stage from pointers (the previous form) a stage paid 6 (cv6) to 36 (cv4) vector adds on the pipe
+// its MFMAs need.
+__device__ __forceinline__ f32x4 lds_ld4(unsigned lds_byte) {
+    return *(const __attribute__((address_space(3))) f32x4*)(size_t)lds_byte;
+}
+__device__ __forceinline__ f32x2 lds_ld2(unsigned lds_byte) {
+    return *(const __attribute__((address_space(3))) f32x2*)(size_t)lds_byte;
+}
+template <class C, int BOFF>
+__device__ __forceinline__ void compute_stage(unsigned a_addr, const unsigned (&tap)[C::KW],
+                                              f32x16 (&acc)[C::MT][C::RT][C::CT]) {
+    // steps k = (channel pair, kernel column); the operands of step k + 1 are requested before the MFMAs of step k
+    constexpr int K2 = (C::CK / 2) * C::KW;
+    float a[2][C::MT], b[2][C::RT][C::CT];
+    auto fetch = [&](int k, float (&av)[C::MT], float (&bv)[C::RT][C::CT]) {
+        const int cp = k / C::KW, s = k % C::KW;
+        const unsigned ap = a_addr + k * (C::WM * 64 * C::MT) * 4;
+        if constexpr (C::MT == 4) {
+            const f32x4 v = lds_ld4(ap);
+            av[0] = v[0]; av[1] = v[1]; av[2] = v[2]; av[3] = v[3];
+        } else if constexpr (C::MT == 2) {
+            const f32x2 v = lds_ld2(ap);
+            av[0] = v[0]; av[1] = v[1];
+        } else {
+            av[0] = lds_ld(ap);
+        }
 #pragma unroll
-    for (int cp = 0; cp < C::CK / 2; ++cp) {
+        for (int rt = 0; rt < C::RT; ++rt)
 #pragma unroll
-        for (int s = 0; s < C::KW; ++s) {
-            float a[C::MT];
-            const float* ap = pa + (cp * C::KW + s) * (C::WM * 64 * C::MT);
-            if constexpr (C::MT == 4) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(ap);
-                a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
-            } else if constexpr (C::MT == 2) {
-                const f32x2 v = *reinterpret_cast<const f32x2*>(ap);
-                a[0] = v[0]; a[1] = v[1];
-            } else {
-                a[0] = *ap;
-            }
-            float b[C::RT][C::CT];
+            for (int ct = 0; ct < C::CT; ++ct)
+                bv[rt][ct] = lds_ld(tap[s] + BOFF + (2 * cp * C::PS + rt * C::PCW + ct * 32) * 4);
+    };
+    fetch(0, a[0], b[0]);
+#pragma unroll
+    for (int k = 0; k < K2; ++k) {
+        if (k + 1 < K2) fetch(k + 1, a[(k + 1) & 1], b[(k + 1) & 1]);
+#pragma unroll
+        for (int m = 0; m < C::MT; ++m)
 #pragma unroll
             for (int rt = 0; rt < C::RT; ++rt)
 #pragma unroll
                 for (int ct = 0; ct < C::CT; ++ct)
-                    b[rt][ct] = pb[2 * cp * C::PS + rt * C::PCW + ct * 32 + (C::DILMAX ? s * dil : s)];
-#pragma unroll
-            for (int m = 0; m < C::MT; ++m)
-#pragma unroll
-                for (int rt = 0; rt < C::RT; ++rt)
-#pragma unroll
-                    for (int ct = 0; ct < C::CT; ++ct)
-                        acc[m][rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[rt][ct], acc[m][rt][ct], 0, 0, 0);
-        }
+                    acc[m][rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k & 1][m], b[k & 1][rt][ct], acc[m][rt][ct], 0, 0, 0);
     }
 }
 
 // HET layout (see ConvCfg): one stage for a wave of type A (4 channel tiles x 1 column tile) or B (1 x 3).
-template <class C>
-__device__ __forceinline__ void compute_stage_het(const float* __restrict__ pa, const float* __restrict__ pb,
-                                                  f32x16 (&acc)[4], int dil, bool type_a) {
+template <class C, int BOFF>
+__device__ __forceinline__ void compute_stage_het(unsigned a_addr, const unsigned (&tap)[C::KW], f32x16 (&acc)[4], bool type_a) {
     if (type_a) {
 #pragma unroll
         for (int cp = 0; cp < C::CK / 2; ++cp)
 #pragma unroll
             for (int s = 0; s < C::KW; ++s) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(pa + (cp * C::KW + s) * 256);
-                const float b = pb[2 * cp * C::PS + s * dil];
+                const f32x4 a = lds_ld4(a_addr + (cp * C::KW + s) * 1024);
+                const float b = lds_ld(tap[s] + BOFF + 2 * cp * C::PS * 4);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b, acc[m], 0, 0, 0);
             }
@@ -269,10 +284,10 @@ __device__ __forceinline__ void compute_stage_het(const float* __restrict__ pa, 
         for (int cp = 0; cp < C::CK / 2; ++cp)
 #pragma unroll
             for (int s = 0; s < C::KW; ++s) {
-                const float a = pa[(cp * C::KW + s) * 256];
+                const float a = lds_ld(a_addr + (cp * C::KW + s) * 1024);
                 float b[3];
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) b[ct] = pb[2 * cp * C::PS + ct * 32 + s * dil];
+                for (int ct = 0; ct < 3; ++ct) b[ct] = lds_ld(tap[s] + BOFF + (2 * cp * C::PS + ct * 32) * 4);
 #pragma unroll
                 for (int ct = 0; ct < 3; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[ct], acc[ct], 0, 0, 0);
             }
@@ -338,22 +353,54 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
     load_patch<C>(plan, xn, 0, T, patch(0), wid);
     load_slab<C>(wbase, slab(0), wid, lane);
 
-    int st = 0;
-    for (int cc = 0; cc < C::NCC; ++cc) {
-        for (int r = 0; r < C::KH; ++r, ++st) {
-            wait_vm0();
-            __syncthreads();
-            if (st + 1 < C::NST) {
-                load_slab<C>(wbase + (size_t)(st + 1) * C::SLAB, slab(st + 1), wid, lane);
-                if (r == C::KH - 1) load_patch<C>(plan, xn, cc + 1, T, patch(cc + 1), wid);
-            }
+    // operand base addresses (see compute_stage): A per slab buffer, B per kernel column in patch buffer 0
+    unsigned a_addr[2], tap[C::KW];
+    a_addr[0] = lds_addr(slab(0)) + abase * 4;
+    a_addr[1] = lds_addr(slab(1)) + abase * 4;
+#pragma unroll
+    for (int s = 0; s < C::KW; ++s) tap[s] = lds_addr(patch(0)) + (bbase + (C::DILMAX ? s * dil : s)) * 4;
+    constexpr int PBYTES = C::PATCH * 4;
+
+    // one stage of the K loop; PAR >= 0: buffer parity known at compile time (an immediate), -1: run-time parity
+    auto stage = [&](auto PARC, int st, int cc, int r) {
+        constexpr int PAR = decltype(PARC)::value;
+        wait_vm0();
+        __syncthreads();
+        if (st + 1 < C::NST) {
+            load_slab<C>(wbase + (size_t)(st + 1) * C::SLAB, slab(st + 1), wid, lane);
+            if (r == C::KH - 1) load_patch<C>(plan, xn, cc + 1, T, patch(cc + 1), wid);
+        }
+        if constexpr (PAR >= 0) {
             if constexpr (C::HET) {
                 f32x16(&hacc)[4] = *reinterpret_cast<f32x16(*)[4]>(&acc[0][0][0]);
-                compute_stage_het<C>(slab(st) + abase, patch(cc) + bbase, hacc, dil, type_a);
+                compute_stage_het<C, PAR * PBYTES>(a_addr[PAR], tap, hacc, type_a);
             } else {
-                compute_stage<C>(slab(st) + abase, patch(cc) + bbase + r * C::PCW, acc, dil);
+                compute_stage<C, PAR * PBYTES>(a_addr[PAR], tap, acc);
+            }
+        } else {
+            unsigned tr[C::KW];
+            const unsigned boff = (cc & 1) * PBYTES + r * C::PCW * 4;
+#pragma unroll
+            for (int s = 0; s < C::KW; ++s) tr[s] = tap[s] + boff;
+            if constexpr (C::HET) {
+                f32x16(&hacc)[4] = *reinterpret_cast<f32x16(*)[4]>(&acc[0][0][0]);
+                compute_stage_het<C, 0>(a_addr[st & 1], tr, hacc, type_a);
+            } else {
+                compute_stage<C, 0>(a_addr[st & 1], tr, acc);
             }
         }
+    };
+    if constexpr (C::KH == 1 && C::NCC % 2 == 0) {
+        // the frequency-domain use (and cv7 / cv8): stage = channel chunk, two per trip, so that the double buffers'
+        // parity is part of the immediates
+        for (int cc = 0; cc < C::NCC; cc += 2) {
+            stage(std::integral_constant<int, 0>{}, cc, cc, 0);
+            stage(std::integral_constant<int, 1>{}, cc + 1, cc + 1, 0);
+        }
+    } else {
+        int st = 0;
+        for (int cc = 0; cc < C::NCC; ++cc)
+            for (int r = 0; r < C::KH; ++r, ++st) stage(std::integral_constant<int, -1>{}, st, cc, r);
     }
 
     if constexpr (C::HET) {
