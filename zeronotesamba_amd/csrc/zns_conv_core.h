@@ -266,10 +266,12 @@ __device__ __forceinline__ void compute_stage(unsigned a_addr, const unsigned (&
     }
 }
 
-// HET layout (see ConvCfg): one stage for a wave of type A (4 channel tiles x 1 column tile) or B (1 x 3).
-template <class C, int BOFF>
-__device__ __forceinline__ void compute_stage_het(unsigned a_addr, const unsigned (&tap)[C::KW], f32x16 (&acc)[4], bool type_a) {
-    if (type_a) {
+// HET layout (see ConvCfg): one stage for a wave of type A (TA: 4 channel tiles x 1 column tile) or B (1 x 3).  The
+// wave kind is a template argument: the whole K loop is instantiated once per kind (a run-time branch inside the loop
+// makes the two kinds' accumulators meet in a copy -- 24 v_mov_b64 per stage).
+template <class C, int BOFF, bool TA>
+__device__ __forceinline__ void compute_stage_het(unsigned a_addr, const unsigned (&tap)[C::KW], f32x16 (&acc)[4]) {
+    if constexpr (TA) {
 #pragma unroll
         for (int cp = 0; cp < C::CK / 2; ++cp)
 #pragma unroll
@@ -359,11 +361,18 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
     a_addr[1] = lds_addr(slab(1)) + abase * 4;
 #pragma unroll
     for (int s = 0; s < C::KW; ++s) tap[s] = lds_addr(patch(0)) + (bbase + (C::DILMAX ? s * dil : s)) * 4;
+    // opaque: the registers hold the FULL addresses (the compiler would otherwise keep the variable part and re-add the
+    // buffer's constant offset, which is beyond the reads' 16-bit immediate in the large-slab layouts, per use)
+    asm volatile("" : "+v"(a_addr[0]), "+v"(a_addr[1]));
+#pragma unroll
+    for (int s = 0; s < C::KW; ++s) asm volatile("" : "+v"(tap[s]));
     constexpr int PBYTES = C::PATCH * 4;
 
-    // one stage of the K loop; PAR >= 0: buffer parity known at compile time (an immediate), -1: run-time parity
-    auto stage = [&](auto PARC, int st, int cc, int r) {
+    // one stage of the K loop; PAR >= 0: buffer parity known at compile time (an immediate), -1: run-time parity;
+    // TAC: the wave kind of the two-kind layout
+    auto stage = [&](auto PARC, auto TAC, int st, int cc, int r) {
         constexpr int PAR = decltype(PARC)::value;
+        constexpr bool TA = decltype(TAC)::value;
         wait_vm0();
         __syncthreads();
         if (st + 1 < C::NST) {
@@ -373,7 +382,7 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
         if constexpr (PAR >= 0) {
             if constexpr (C::HET) {
                 f32x16(&hacc)[4] = *reinterpret_cast<f32x16(*)[4]>(&acc[0][0][0]);
-                compute_stage_het<C, PAR * PBYTES>(a_addr[PAR], tap, hacc, type_a);
+                compute_stage_het<C, PAR * PBYTES, TA>(a_addr[PAR], tap, hacc);
             } else {
                 compute_stage<C, PAR * PBYTES>(a_addr[PAR], tap, acc);
             }
@@ -384,23 +393,31 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
             for (int s = 0; s < C::KW; ++s) tr[s] = tap[s] + boff;
             if constexpr (C::HET) {
                 f32x16(&hacc)[4] = *reinterpret_cast<f32x16(*)[4]>(&acc[0][0][0]);
-                compute_stage_het<C, 0>(a_addr[st & 1], tr, hacc, type_a);
+                compute_stage_het<C, 0, TA>(a_addr[st & 1], tr, hacc);
             } else {
                 compute_stage<C, 0>(a_addr[st & 1], tr, acc);
             }
         }
     };
-    if constexpr (C::KH == 1 && C::NCC % 2 == 0) {
-        // the frequency-domain use (and cv7 / cv8): stage = channel chunk, two per trip, so that the double buffers'
-        // parity is part of the immediates
-        for (int cc = 0; cc < C::NCC; cc += 2) {
-            stage(std::integral_constant<int, 0>{}, cc, cc, 0);
-            stage(std::integral_constant<int, 1>{}, cc + 1, cc + 1, 0);
+    auto k_loop = [&](auto TAC) {
+        if constexpr (C::KH == 1 && C::NCC % 2 == 0) {
+            // the frequency-domain use (and cv7 / cv8): stage = channel chunk, two per trip, so that the double
+            // buffers' parity is part of the immediates
+            for (int cc = 0; cc < C::NCC; cc += 2) {
+                stage(std::integral_constant<int, 0>{}, TAC, cc, cc, 0);
+                stage(std::integral_constant<int, 1>{}, TAC, cc + 1, cc + 1, 0);
+            }
+        } else {
+            int st = 0;
+            for (int cc = 0; cc < C::NCC; ++cc)
+                for (int r = 0; r < C::KH; ++r, ++st) stage(std::integral_constant<int, -1>{}, TAC, st, cc, r);
         }
+    };
+    if constexpr (C::HET) {
+        if (type_a) k_loop(std::true_type{});      // the barriers inside pair up across the two kinds: same trip count
+        else k_loop(std::false_type{});
     } else {
-        int st = 0;
-        for (int cc = 0; cc < C::NCC; ++cc)
-            for (int r = 0; r < C::KH; ++r, ++st) stage(std::integral_constant<int, -1>{}, st, cc, r);
+        k_loop(std::true_type{});
     }
 
     if constexpr (C::HET) {
