@@ -282,17 +282,30 @@ __device__ __forceinline__ void compute_stage_het(unsigned a_addr, const unsigne
                 for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b, acc[m], 0, 0, 0);
             }
     } else {
-#pragma unroll
-        for (int cp = 0; cp < C::CK / 2; ++cp)
+        // Type B waves (one channel tile x three column tiles: four operand reads per three MFMAs) are the youngest
+        // wave of their SIMD and run LAST in every stage (cycle stamps: the three waves of a SIMD multiply one after the
+        // other in age order: done after 10.1 k / 19.1 k / 26.8 k cycles of a 27.3 k-cycle stage), alone on the pipe, so
+        // their own read latency is exposed: a whole channel pair's operands (KW k-steps, 4 KW registers) are requested
+        // ahead of the pair being multiplied; a type B wave has the registers (48 accumulators against type A's 64).
+        float a[2][C::KW], b[2][C::KW][3];
+        auto fetch = [&](int cp, float (&av)[C::KW], float (&bv)[C::KW][3]) {
 #pragma unroll
             for (int s = 0; s < C::KW; ++s) {
-                const float a = lds_ld(a_addr + (cp * C::KW + s) * 1024);
-                float b[3];
+                av[s] = lds_ld(a_addr + (cp * C::KW + s) * 1024);
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct) b[ct] = lds_ld(tap[s] + BOFF + (2 * cp * C::PS + ct * 32) * 4);
-#pragma unroll
-                for (int ct = 0; ct < 3; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[ct], acc[ct], 0, 0, 0);
+                for (int ct = 0; ct < 3; ++ct) bv[s][ct] = lds_ld(tap[s] + BOFF + (2 * cp * C::PS + ct * 32) * 4);
             }
+        };
+        fetch(0, a[0], b[0]);
+#pragma unroll
+        for (int cp = 0; cp < C::CK / 2; ++cp) {
+            if (cp + 1 < C::CK / 2) fetch(cp + 1, a[(cp + 1) & 1], b[(cp + 1) & 1]);
+#pragma unroll
+            for (int s = 0; s < C::KW; ++s)
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cp & 1][s], b[cp & 1][s][ct], acc[ct], 0, 0, 0);
+        }
     }
 }
 
@@ -419,7 +432,6 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
     } else {
         k_loop(std::true_type{});
     }
-
     if constexpr (C::HET) {
         // tile t of this wave: type A -> (channel tile t, column tile wid); type B -> (channel tile wid-8, column tile 8+t)
         const int pp = A.prev_pool;
