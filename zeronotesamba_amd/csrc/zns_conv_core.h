@@ -139,9 +139,11 @@ struct CoreArgs {
 // scalars (base = the chunk's first channel) and one DMA instruction per piece -- nothing on the vector pipe, which in
 // the short-stage layouts (cv5 / cv6: 20 MFMAs per wave and stage) paid 14 address / select instructions per stage for
 // the per-lane 64-bit pointers and zero-page selects this replaced.
+// NWL = number of waves that issue the DMA pieces (all of them, or only the youngest wave of every SIMD: see conv_core)
 template <class C>
 struct PatchPlan {
-    static constexpr int NPI = (C::PATCH / 64 + C::NW - 1) / C::NW;   // 4-byte pieces per wave (16-byte mode uses a quarter)
+    static constexpr int NWL = C::HET ? C::NW - C::HET : C::NW;
+    static constexpr int NPI = (C::PATCH / 64 + NWL - 1) / NWL;       // 4-byte pieces per loader wave (16-byte mode uses a quarter)
     unsigned voff[NPI];
     bool wide;                                                         // 16-byte DMA pieces (wave-uniform)
 };
@@ -153,7 +155,7 @@ __device__ __forceinline__ void patch_offsets(PatchPlan<C>& pl, const float* xn,
     pl.wide = ((T & 3) == 0) && ((reinterpret_cast<uintptr_t>(xn) & 15) == 0);
 #pragma unroll
     for (int i = 0; i < PatchPlan<C>::NPI; ++i) {
-        const int L = ((wid + i * C::NW) * 64 + lane) * (pl.wide ? 4 : 1);
+        const int L = ((wid + i * PatchPlan<C>::NWL) * 64 + lane) * (pl.wide ? 4 : 1);   // wid = loader wave index
         const int ci = L / C::PS;
         const int rem = L - ci * C::PS;
         const int row = rem / C::PCW;
@@ -168,21 +170,22 @@ __device__ __forceinline__ void patch_offsets(PatchPlan<C>& pl, const float* xn,
 template <class C>
 __device__ __forceinline__ void load_patch(const PatchPlan<C>& pl, const float* xn, int cc, int T, float* lds_patch,
                                            int wid) {
+    constexpr int NWL = PatchPlan<C>::NWL;
     const float* base = xn + (size_t)cc * C::CK * C::H * T;
     const __amdgpu_buffer_rsrc_t rs = buf_rsrc(base, (unsigned)((size_t)C::CK * C::H * T * sizeof(float)));
     if (pl.wide) {
         const unsigned dst = lds_addr(lds_patch) + wid * 1024;
 #pragma unroll
         for (int i = 0; i < (PatchPlan<C>::NPI + 3) / 4; ++i) {
-            const int q = wid + i * C::NW;
-            if (q < C::PATCH / 256) blds16a(rs, pl.voff[i], 0, dst + i * C::NW * 1024);
+            const int q = wid + i * NWL;
+            if (q < C::PATCH / 256) blds16a(rs, pl.voff[i], 0, dst + i * NWL * 1024);
         }
     } else {
         const unsigned dst = lds_addr(lds_patch) + wid * 256;
 #pragma unroll
         for (int i = 0; i < PatchPlan<C>::NPI; ++i) {
-            const int q = wid + i * C::NW;
-            if (q < C::PATCH / 64) blds4a(rs, pl.voff[i], dst + i * C::NW * 256);
+            const int q = wid + i * NWL;
+            if (q < C::PATCH / 64) blds4a(rs, pl.voff[i], dst + i * NWL * 256);
         }
     }
 }
@@ -194,7 +197,7 @@ __device__ __forceinline__ void load_slab(const float* wslab, float* lds_slab, i
     constexpr int NI = C::SLAB / 256;
     const __amdgpu_buffer_rsrc_t rs = buf_rsrc(wslab, (unsigned)(C::SLAB * sizeof(float)));
     const unsigned dst = lds_addr(lds_slab);
-    for (int q = wid; q < NI; q += C::NW) blds16a(rs, (unsigned)lane * 16u, (unsigned)q * 1024u, dst + q * 1024);
+    for (int q = wid; q < NI; q += PatchPlan<C>::NWL) blds16a(rs, (unsigned)lane * 16u, (unsigned)q * 1024u, dst + q * 1024);
 }
 
 // Epilogue helper: one 32x32 accumulator tile -> global rows of `ld` floats, through a per-wave LDS tile so that every
@@ -362,11 +365,18 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
     const int bbase = C::HET ? lane_h * C::PS + (type_a ? wid : C::HET) * 32 + lane_j + (pw_al - pw)
                              : lane_h * C::PS + (wr * C::RT) * C::PCW + wc * C::CT * 32 + lane_j + (pw_al - pw);
 
+    // Who issues the DMA pieces: in the two-kind layout only the type B waves -- the youngest wave of every SIMD, which
+    // multiplies LAST in a stage (the waves of a SIMD run in age order) and would otherwise wait; the type A waves start
+    // their MFMAs right after the barrier.  Elsewhere every wave issues its share.
+    const bool loader = !C::HET || !type_a;
+    const int lw = C::HET ? wid - C::HET : wid;          // loader wave index
     PatchPlan<C> plan;
-    patch_offsets<C>(plan, xn, h0, w0, T, wid, lane, pw_al,
-                     (C::DILMAX ? C::WB + (C::KW - 1) * dil : C::WB + C::KW - 1) + (pw_al - pw));
-    load_patch<C>(plan, xn, 0, T, patch(0), wid);
-    load_slab<C>(wbase, slab(0), wid, lane);
+    if (loader) {
+        patch_offsets<C>(plan, xn, h0, w0, T, lw, lane, pw_al,
+                         (C::DILMAX ? C::WB + (C::KW - 1) * dil : C::WB + C::KW - 1) + (pw_al - pw));
+        load_patch<C>(plan, xn, 0, T, patch(0), lw);
+        load_slab<C>(wbase, slab(0), lw, lane);
+    }
 
     // operand base addresses (see compute_stage): A per slab buffer, B per kernel column in patch buffer 0
     unsigned a_addr[2], tap[C::KW];
@@ -388,9 +398,9 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
         constexpr bool TA = decltype(TAC)::value;
         wait_vm0();
         __syncthreads();
-        if (st + 1 < C::NST) {
-            load_slab<C>(wbase + (size_t)(st + 1) * C::SLAB, slab(st + 1), wid, lane);
-            if (r == C::KH - 1) load_patch<C>(plan, xn, cc + 1, T, patch(cc + 1), wid);
+        if ((!C::HET || !TA) && st + 1 < C::NST) {
+            load_slab<C>(wbase + (size_t)(st + 1) * C::SLAB, slab(st + 1), lw, lane);
+            if (r == C::KH - 1) load_patch<C>(plan, xn, cc + 1, T, patch(cc + 1), lw);
         }
         if constexpr (PAR >= 0) {
             if constexpr (C::HET) {
