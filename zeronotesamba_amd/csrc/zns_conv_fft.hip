@@ -423,9 +423,32 @@ __global__ void __launch_bounds__(256) pack_freq_weights_kernel(Ptr2 w, float* _
 // rows g, g+4, ...; the kw lags of every (ci, row) go through an LDS tile [32][kh][kw] that is then written out as ONE
 // contiguous run of dW (32 * kh * kw floats) -- the first version had each thread write its kw floats at a stride of
 // kh * kw floats from its neighbour (64 partial lines per store instruction): 0.45 ms per step for 0.1 GB of results.
+// The launch also carries the bias gradient: blocks past `rblocks` (one per (branch, output channel)) sum slot 0 "re" of
+// the zero-padded dZ blocks' spectrum (`sz`: each block's sum) over samples and positions -- as its own launch this
+// was 16 us of latency five times per step; here it rides beside the slab reduction.
 __global__ void __launch_bounds__(128) wgrad_spec_reduce_kernel(const float* __restrict__ slab, MPtr2 dw, int KS, int cout,
-                                                                int cin, int kh, int kw, int accumulate, int nbr) {
+                                                                int cin, int kh, int kw, int accumulate, int nbr,
+                                                                const float* __restrict__ sz, MPtr2 db, int Bs, int P,
+                                                                int rblocks) {
     extern __shared__ float tile[];                 // [32][kh][kw]
+    if ((int)blockIdx.x >= rblocks) {
+        const int co = ((int)blockIdx.x - rblocks) % cout, br = ((int)blockIdx.x - rblocks) / cout;
+        float acc = 0.f;
+        for (int b = 0; b < Bs; ++b) {
+            const float* sp = sz + (((size_t)(br * Bs + b) * FS) * cout + co) * P;
+            for (int p = threadIdx.x; p < P; p += 128) acc += sp[p];
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if ((threadIdx.x & 63) == 0) tile[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float s = tile[0] + tile[1];
+            float* d = db.p[br] + co;
+            *d = accumulate ? *d + s : s;
+        }
+        return;
+    }
     const int cib = cin / 32;
     int bid = blockIdx.x;
     const int cb = bid % cib; bid /= cib;
@@ -471,27 +494,6 @@ __global__ void __launch_bounds__(128) wgrad_spec_reduce_kernel(const float* __r
     const int n = 32 * kh * kw;
     float* d = dw.p[br] + ((size_t)co * cin + cb * 32) * kh * kw;
     for (int i = threadIdx.x; i < n; i += 128) d[i] = accumulate ? d[i] + tile[i] : tile[i];
-}
-
-// bias gradient from the spectrum of the zero-padded dZ blocks: slot 0 "re" is each block's sum
-__global__ void __launch_bounds__(256) spec_dc_sum_kernel(const float* __restrict__ sz, MPtr2 db, int B, int C, int P,
-                                                          int accumulate) {
-    __shared__ float red[4];
-    const int co = blockIdx.x % C, br = blockIdx.x / C;
-    float acc = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float* sp = sz + (((size_t)(br * B + b) * FS) * C + co) * P;
-        for (int p = threadIdx.x; p < P; p += 256) acc += sp[p];
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float s = red[0] + red[1] + red[2] + red[3];
-        float* d = db.p[br] + co;
-        *d = accumulate ? *d + s : s;
-    }
 }
 
 // =====================================================================================================
@@ -793,9 +795,6 @@ static int fft_wgrad_t(const ConvArgs& a, const float* dz, const float* x, MPtr2
     else
         rc = run_spec_fwd(dz, sz, g.nb, a.cout, a.H, a.T, g, 0, g.V, -1.f, st);  // zero-padded V-blocks of dZ: (r, i, r-i)
     if (rc) return rc;
-    hipLaunchKernelGGL(spec_dc_sum_kernel, dim3(a.nbr * a.cout), dim3(256), 0, st, (const float*)sz, db, g.Bs, a.cout,
-                       g.P, accumulate);
-    ZNS_LAUNCH_CHECK();
     rc = set_lds_fw<W>(wgrad_core<W>);
     if (rc) return rc;
     WgArgs A{};
@@ -816,8 +815,9 @@ static int fft_wgrad_t(const ConvArgs& a, const float* dz, const float* x, MPtr2
     ZNS_LAUNCH_CHECK();
     if (probe) { ZNS_HIP(hipEventRecord(g_probe.stop[slot], st)); ++g_probe.count; }
     const int rblocks = a.nbr * a.cout * (a.cin / 32);
-    hipLaunchKernelGGL(wgrad_spec_reduce_kernel, dim3(rblocks), dim3(128), (size_t)32 * a.kh * a.kw * sizeof(float), st,
-                       (const float*)slab, dw, A.KS, a.cout, a.cin, a.kh, a.kw, accumulate, a.nbr);
+    hipLaunchKernelGGL(wgrad_spec_reduce_kernel, dim3(rblocks + a.nbr * a.cout), dim3(128),
+                       (size_t)32 * a.kh * a.kw * sizeof(float), st, (const float*)slab, dw, A.KS, a.cout, a.cin, a.kh, a.kw,
+                       accumulate, a.nbr, (const float*)sz, db, g.Bs, g.P, rblocks);
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
 }
