@@ -26,17 +26,31 @@ __device__ inline float block_sum(float v, float* red) {
 }
 
 // ------------------------------------------------------------------ head (models.py:99-101)
-__global__ void head_fwd_kernel(int B, int T, int C, const float* __restrict__ h, Ptr2 w, Ptr2 b,
-                                float* __restrict__ emb, int total) {
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= total) return;
-    const int t = o % T, n = o / T, br = n / B;
-    const float* hp = h + (size_t)n * C * T + t;
-    const float* wp = w.p[br];
+// Block = 64 consecutive (n, t) positions x 4 channel quarters: a thread sums a quarter of the channels (independent
+// loads, 8 in flight), the quarters are added in a fixed order.  (One thread per position walking all C channels was 34 us
+// of load latency on 64 blocks.)
+__global__ void __launch_bounds__(256) head_fwd_kernel(int B, int T, int C, const float* __restrict__ h, Ptr2 w, Ptr2 b,
+                                                       float* __restrict__ emb, int total) {
+    __shared__ float part[4][64];
+    const int tl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int o = blockIdx.x * 64 + tl;
     float acc = 0.f;
-    for (int c = 0; c < C; ++c) acc = fmaf(hp[(size_t)c * T], wp[c], acc);
-    acc += b.p[br][0];
-    emb[o] = 1.0f / (1.0f + expf(-acc));
+    int br = 0;
+    if (o < total) {
+        const int t = o % T, n = o / T;
+        br = n / B;
+        const float* hp = h + (size_t)n * C * T + t;
+        const float* wp = w.p[br];
+        const int cpg = (C + 3) / 4, c0 = g * cpg, c1 = c0 + cpg < C ? c0 + cpg : C;
+#pragma unroll 8
+        for (int c = c0; c < c1; ++c) acc = fmaf(hp[(size_t)c * T], wp[c], acc);
+    }
+    part[g][tl] = acc;
+    __syncthreads();
+    if (g == 0 && o < total) {
+        const float s = ((part[0][tl] + part[1][tl]) + part[2][tl]) + part[3][tl] + b.p[br][0];
+        emb[o] = 1.0f / (1.0f + expf(-s));
+    }
 }
 
 // one block per (n, c): writes dz row, partial dw; c==0 block also writes the partial db
@@ -419,7 +433,7 @@ int zns_head_fwd_f32(int nbr, int B, int T, int C, const float* h, const float* 
     Ptr2 pw{}, pb{};
     for (int i = 0; i < nbr; ++i) { pw.p[i] = w[i]; pb.p[i] = b[i]; }
     const int total = nbr * B * T;
-    hipLaunchKernelGGL(head_fwd_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, T, C, h, pw,
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((total + 63) / 64), dim3(256), 0, (hipStream_t)stream, B, T, C, h, pw,
                        pb, emb, total);
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
