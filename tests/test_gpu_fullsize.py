@@ -295,7 +295,10 @@ def test_finetune_step_full_size_against_the_cpu_oracle(red):
     n_all = n_bad = 0
     for k, v in d.named_parameters():
         got, want = v.detach().cpu(), after_ref[k]
-        assert (got - want).abs().max().item() <= 1e-5 * max(want.abs().max().item(), 1e-3), k
+        # 1e-5 of the tensor's scale -- but never tighter than one sign flip of a near-zero gradient element (2 lr: Adam's
+        # first step is lr * sign(g)), which the count below bounds to 0.1 % of the elements
+        worst_p = (got - want).abs().max().item()
+        assert worst_p <= max(1e-5 * max(want.abs().max().item(), 1e-3), 2.2 * lr), (k, worst_p)
         # the update: both sides moved by lr * g / (|g| + eps); elements whose gradient is within the 1e-4 disagreement
         # of zero may take the other sign (2 * lr apart), everything else must agree to a tenth of lr
         dd, dr = (got - before[k]).double(), (want - before[k]).double()

@@ -131,6 +131,7 @@ struct InvEpi {
     const uint8_t* prev_argmax;
     int prev_pool;
     uint32_t mV, mNB, mHq;     // ceil(2^32 / d) for the epilogue's index divisions (exact for x * d < 2^32)
+    uint32_t mT, mPP;          // FLAT epilogue: divisions by T and by prev_pool
 };
 
 constexpr int IVMAX = FN - 12;     // V <= 52 (kw >= 13)
@@ -161,7 +162,7 @@ __device__ __forceinline__ typename VecOf<VW>::type ld_stage(const float* sp) {
     }
 }
 
-template <int MODE, int VW, bool ROW = false>
+template <int MODE, int VW, bool ROW = false, bool FLAT = false>
 __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__ S, float* __restrict__ out, int C, int H,
                                                        int T, int V, int NB, int chunks, int WPB, int NS, InvEpi E) {
     extern __shared__ __attribute__((aligned(16))) float stage[];   // [256][VS], VS odd: per-lane rows hit distinct banks
@@ -202,6 +203,109 @@ __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__
     const int nout = (nwin / pool) * V;
     const int br = n / (MODE == 1 ? E.B : 1), bb = n - br * (MODE == 1 ? E.B : 1);
     const uint32_t lseed = MODE == 1 ? layer_seed(E.seed, E.layer, br) : 0u;
+    if constexpr (FLAT) {
+        // Rows whose length is not a multiple of 4 (T = 313, the reference's tile): the block's outputs are still ONE
+        // contiguous run of memory -- (pooled) rows x [prev_pool rows] x T -- so it is cut into 16-byte chunks aligned in
+        // GLOBAL memory; a chunk's four elements may sit in two rows, each is located (one division per chunk, then
+        // increments) and read from the LDS tile on its own.  One-segment rows only (NS = 1).  With 4-byte stores these
+        // launches cost 1.45x their T = 512 time per byte.
+        const int pp = MODE == 2 ? E.prev_pool : 1;
+        const int nrows = nwin / group;
+        const int count = nrows * pp * T;
+        const size_t g0 = ((size_t)n * C * Hq + Rq0) * pp * T;
+        const int shift = (int)(g0 & 3);
+        const int nchunk = (count + shift + 3) >> 2;
+        constexpr int EV = 2;                          // two chunks per thread and trip: all global loads before the stores
+        for (int e0 = threadIdx.x; e0 < nchunk; e0 += 256 * EV) {
+            float r[EV][4], mk[EV][4];
+            int am[EV][4], qq[EV][4], Rqv[EV][4], colv[EV][4];
+            bool okv[EV][4];
+#pragma unroll
+            for (int u = 0; u < EV; ++u) {
+                const int f0 = 4 * (e0 + u * 256) - shift;
+                int rowo = fastdiv(f0 < 0 ? 0 : f0, T, E.mT);
+                int col = (f0 < 0 ? 0 : f0) - rowo * T + (f0 < 0 ? f0 : 0);     // negative only in the block's first chunk
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int f = f0 + k;
+                    okv[u][k] = e0 + u * 256 < nchunk && f >= 0 && f < count;
+                    r[u][k] = 0.f; mk[u][k] = 1.f; am[u][k] = 0; qq[u][k] = 0; Rqv[u][k] = 0; colv[u][k] = col;
+                    if (okv[u][k]) {
+                        const int rin = pp > 1 ? fastdiv(rowo, pp, E.mPP) : rowo;
+                        qq[u][k] = rowo - rin * pp;
+                        Rqv[u][k] = Rq0 + rin;
+                        const float* sp = stage + rin * group * VS + col;
+                        float rv = sp[0];
+                        int av = 0;
+                        for (int a = 1; a < pool; ++a) {
+                            const float t = sp[a * NB * VS];
+                            if (t > rv) { rv = t; av = a; }
+                        }
+                        r[u][k] = rv;
+                        am[u][k] = av;
+                        if (MODE == 1) mk[u][k] = E.bias.p[br][fastdiv(Rqv[u][k], Hq, E.mHq)];
+                        if (MODE == 2 && pp > 1) {
+                            const size_t oin = ((size_t)n * C * Hq + Rqv[u][k]) * T + col;
+                            if (E.xmask) mk[u][k] = E.xmask[oin];
+                            am[u][k] = E.prev_argmax[oin];
+                        }
+                    }
+                    if (++col >= T) { col = 0; ++rowo; }
+                }
+                if (MODE == 2 && pp == 1 && E.xmask) {      // the mask has the output's layout: one aligned 16-byte load
+                    if (okv[u][0] && okv[u][3]) {
+                        const f32x4 m4 = *reinterpret_cast<const f32x4*>(E.xmask + g0 + f0);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) mk[u][k] = m4[k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (okv[u][k]) mk[u][k] = E.xmask[g0 + f0 + k];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < EV; ++u) {
+                const int f0 = 4 * (e0 + u * 256) - shift;
+                f32x4 val;
+                uint32_t amw = 0u;
+                bool any = false, all = true;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float t = r[u][k];
+                    if (MODE == 1) {
+                        t += mk[u][k];
+                        t = t > 0.f ? t : 0.f;
+                        if (E.thresh) {
+                            const uint64_t idx = ((uint64_t)bb * C * Hq + Rqv[u][k]) * T + colv[u][k];
+                            t = drop_keep(lseed, idx, E.thresh) ? t * E.inv_keep : 0.f;
+                        }
+                        amw |= (uint32_t)am[u][k] << (8 * k);
+                    } else if (MODE == 2) {
+                        if (E.xmask) t = (mk[u][k] != 0.f) ? t * E.inv_keep : 0.f;
+                        if (pp > 1) t = (am[u][k] == qq[u][k]) ? t : 0.f;
+                    }
+                    val[k] = t;
+                    any = any || okv[u][k];
+                    all = all && okv[u][k];
+                }
+                if (!any) continue;
+                float* d = out + g0 + f0;
+                if (all) {
+                    *reinterpret_cast<f32x4*>(d) = val;
+                    if (MODE == 1 && E.argmax && pool > 1) *reinterpret_cast<uint32_t*>(E.argmax + g0 + f0) = amw;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (okv[u][k]) {
+                            d[k] = val[k];
+                            if (MODE == 1 && E.argmax && pool > 1) E.argmax[g0 + f0 + k] = (uint8_t)(amw >> (8 * k));
+                        }
+                }
+            }
+        }
+        return;
+    }
     if constexpr (VW > 1) {
         typedef typename VecOf<VW>::type vec_t;
         typedef typename VecOf<VW>::amtype am_t;
@@ -666,7 +770,15 @@ static int run_spec_inv(const float* S, float* out, int nb, int C, int H, int T,
     E.mHq = div_magic(H / pool);
     const size_t lds = (size_t)256 * (vw > 1 ? g.V : (g.V | 1)) * sizeof(float);
     const dim3 grid((unsigned)((size_t)nb * chunks));
-    if (row)
+    // everything else on a one-segment row (odd T, e.g. the reference's 313 frames): 16-byte chunks of the block's flat output
+    const bool flat = !row && vw < 4 && g.NS == 1 && al(out, 16) && al(E.argmax, 4) && al(E.xmask, 16);
+    E.mT = div_magic(T);
+    E.mPP = div_magic(MODE == 2 ? E.prev_pool : 1);
+    if (flat) {
+        const size_t lds_f = (size_t)256 * g.V * sizeof(float);      // LDS row stride V (as VW > 1)
+        hipLaunchKernelGGL((spec_inv_kernel<MODE, 4, false, true>), grid, dim3(256), lds_f, st, S, out, C, H, T, g.V, g.NB,
+                           chunks, WPB, g.NS, E);
+    } else if (row)
         hipLaunchKernelGGL((spec_inv_kernel<MODE, 4, true>), grid, dim3(256), lds, st, S, out, C, H, T, g.V, g.NB, chunks, WPB, g.NS, E);
     else if (vw == 4)
         hipLaunchKernelGGL((spec_inv_kernel<MODE, 4>), grid, dim3(256), lds, st, S, out, C, H, T, g.V, g.NB, chunks, WPB, g.NS, E);
