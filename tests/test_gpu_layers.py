@@ -58,7 +58,10 @@ def test_conv_layer_at_bench_shapes(li, T):
 # the direct kernels), widths that are not a multiple of 4 (no 16-byte row alignment anywhere), a one-window row, a lone
 # branch with an odd batch, and a 60 s clip (T = 3751: NS = 7..8 row segments per sample).
 RAGGED = [(1, 31, 2, 1), (1, 32, 1, 3), (2, 33, 2, 1), (3, 45, 1, 1), (4, 97, 2, 1), (5, 35, 1, 2), (6, 50, 2, 1),
-          (3, 3751, 1, 1), (1, 2501, 1, 1)]
+          (3, 3751, 1, 1), (1, 2501, 1, 1),
+          # every residue of T mod 4 through the flat 16-byte epilogue of the inverse transform (one-segment rows), with
+          # and without pooling / unpooling, and an odd two-segment row (T = 627: the scalar epilogue)
+          (1, 34, 1, 2), (2, 39, 2, 1), (3, 66, 2, 1), (4, 47, 1, 1), (5, 121, 2, 1), (2, 627, 1, 1)]
 
 
 @pytest.mark.parametrize("li,T,nbr,B", RAGGED)
