@@ -1,6 +1,8 @@
 // cv1: Conv2d(1 -> 64, (3,11), padding (1,5)) + ReLU + Dropout  (models.py:16,37-39) and its weight gradient.
-// K = 33 only, so this layer is HBM-bound (201 MB of output per branch at B=16, T=512): direct convolution,
-// 16-byte stores along T, weights read through the scalar cache.  No MFMA on purpose.
+// K = 33 only, so this layer is HBM-bound by SURVEY 8(d) (201 MB of output per branch at B=16, T=512) -- but the vector
+// pipe binds it first: 33 FMAs + a 3-integer-multiply dropout hash (quarter rate: worth ~24 more) per output.  The
+// forward kernel therefore takes the FMAs to the matrix pipe (a 64 x 34 x pixels GEMM: half their vector-pipe time, and on
+// gfx950 the two pipes of a SIMD do not overlap, so it is time saved, not hidden); bias / ReLU / hash stay vector work.
 #include "zns_common.h"
 #include "zns_kernels.h"
 
@@ -8,59 +10,90 @@ namespace zns {
 
 constexpr int CV1_KH = 3, CV1_KW = 11, CV1_CO = 64;
 
-// thread -> (n, h, 4 consecutive t); loops over the 64 output channels
+typedef float c1_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int C1_TB = 256;                 // pixels of one image row per block
+constexpr int C1_RS = C1_TB + 16;          // LDS row stride (>= C1_TB + 10)
+constexpr int C1_STEPS = (CV1_KH * CV1_KW + 1) / 2;     // 17 k-steps of 2 taps (the 34th tap is a zero weight)
+
+// Block = (sample n, row h, 256 pixels): the three input rows are staged once (zero padded); a wave takes 32-pixel
+// groups: M = 64 output channels (two 32 x 32 accumulators), K = 34 taps, N = 32 pixels.  A (the weights) lives in
+// registers for the whole kernel; B is one LDS read per k-step at a per-lane tap offset computed once.  Epilogue on the
+// accumulators: bias, ReLU, dropout hash of the output's linear index, 4-byte buffer stores (32 consecutive pixels of one
+// channel per half wave = 128-byte runs; the channel goes into the scalar offset, out-of-row lanes out of range).
 __global__ void __launch_bounds__(256) cv1_fwd_kernel(int B, int T, int H, const float* __restrict__ x, Ptr2 w,
                                                       Ptr2 bias, float* __restrict__ y, uint32_t thresh,
-                                                      float inv_keep, uint32_t seed, int layer, int T4,
-                                                      long long total) {
-    const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= total) return;
-    const int t0 = (int)(o % T4) * 4;
-    const int h = (int)((o / T4) % H);
-    const int n = (int)(o / ((long long)T4 * H));
+                                                      float inv_keep, uint32_t seed, int layer, int tblocks) {
+    __shared__ float sx[CV1_KH * C1_RS];
+    int bid = blockIdx.x;
+    const int tb = bid % tblocks; bid /= tblocks;
+    const int h = bid % H;
+    const int n = bid / H;
     const int br = n / B, b = n % B;
-    float xin[CV1_KH][4 + CV1_KW - 1];
-#pragma unroll
-    for (int r = 0; r < CV1_KH; ++r) {
-        const int hh = h + r - 1;
-#pragma unroll
-        for (int c = 0; c < 4 + CV1_KW - 1; ++c) {
-            const int tt = t0 + c - 5;
-            xin[r][c] = (hh >= 0 && hh < H && tt >= 0 && tt < T) ? x[((size_t)n * H + hh) * T + tt] : 0.f;
-        }
+    const int t_blk = tb * C1_TB;
+    for (int i = threadIdx.x; i < CV1_KH * (C1_TB + CV1_KW - 1); i += 256) {
+        const int r = i / (C1_TB + CV1_KW - 1), c = i - r * (C1_TB + CV1_KW - 1);
+        const int hh = h + r - 1, tt = t_blk + c - CV1_KW / 2;
+        sx[r * C1_RS + c] = (hh >= 0 && hh < H && tt >= 0 && tt < T) ? x[((size_t)n * H + hh) * T + tt] : 0.f;
     }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int half = lane >> 5, px = lane & 31;
     const float* wb = w.p[br];
-    const float* bb = bias.p[br];
+    float a0[C1_STEPS], a1[C1_STEPS], bv[2][16];
+    int off[C1_STEPS];
+#pragma unroll
+    for (int st = 0; st < C1_STEPS; ++st) {
+        const int kk = 2 * st + half;
+        const bool real = kk < CV1_KH * CV1_KW;
+        a0[st] = real ? wb[px * (CV1_KH * CV1_KW) + kk] : 0.f;
+        a1[st] = real ? wb[(px + 32) * (CV1_KH * CV1_KW) + kk] : 0.f;
+        const int kq = real ? kk : 0;
+        off[st] = (kq / CV1_KW) * C1_RS + kq % CV1_KW + px;
+    }
+#pragma unroll
+    for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) bv[tl][k] = bias.p[br][tl * 32 + (k & 3) + 8 * (k >> 2) + 4 * half];
     const uint32_t lseed = layer_seed(seed, layer, br);
-    const bool vec = (T % 4 == 0);
-    for (int co = 0; co < CV1_CO; ++co) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const size_t HT = (size_t)H * T;
+    float* yrow = y + ((size_t)n * CV1_CO * H + h) * T;                    // channel 0 of this (sample, row)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        yrow, 0, (int)(((size_t)(CV1_CO - 1) * HT + T) * sizeof(float)), 0x00020000);
+    __syncthreads();
+    for (int g = wid; g < C1_TB / 32; g += 4) {
+        const int t = t_blk + g * 32 + px;
+        if (t_blk + g * 32 >= T) break;                                    // uniform: the row ends before this group
+        c1_f32x16 acc0, acc1;
 #pragma unroll
-        for (int r = 0; r < CV1_KH; ++r)
+        for (int k = 0; k < 16; ++k) { acc0[k] = 0.f; acc1[k] = 0.f; }
 #pragma unroll
-            for (int s = 0; s < CV1_KW; ++s) {
-                const float wv = wb[co * (CV1_KH * CV1_KW) + r * CV1_KW + s];
+        for (int st = 0; st < C1_STEPS; ++st) {
+            const float bval = sx[off[st] + g * 32];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[st], bval, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[st], bval, acc1, 0, 0, 0);
+        }
+        const unsigned voff = t < T ? (unsigned)(((size_t)(4 * half) * HT + t) * sizeof(float)) : 0x80000000u;
+        // dropout hash of the output's linear index idx0 + dco * HT (hash_u32, zns_common.h), with the two multiplies that
+        // depend only on idx0 done once per group: (lo0 + c) * M = lo0 * M + c * M (mod 2^32, c * M a scalar), and the high
+        // word is hi0 or hi0 + 1.  v_mul_lo_u32 runs at a quarter of the vector rate: four per output were 16 of its ~30
+        // issue slots.
+        const uint64_t idx0 = (((uint64_t)b * CV1_CO + 4 * half) * H + h) * T + t;
+        const uint32_t lo0 = (uint32_t)idx0, hi0 = (uint32_t)(idx0 >> 32);
+        const uint32_t lo0m = lo0 * 0x9E3779B1u, him0 = hi0 * 0x7FEB352Du, him1 = (hi0 + 1u) * 0x7FEB352Du;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) acc[k] = fmaf(xin[r][k + s], wv, acc[k]);
+        for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int dco = tl * 32 + (k & 3) + 8 * (k >> 2);           // channel = dco + 4 * half
+                float v = (tl ? acc1[k] : acc0[k]) + bv[tl][k];
+                v = v > 0.f ? v : 0.f;
+                if (thresh) {
+                    const uint32_t c = (uint32_t)((size_t)dco * HT);             // < 2^32: H * T < 2^26 for any clip
+                    const uint32_t lo = lo0 + c;
+                    const uint32_t hsh = lowbias32((lo0m + c * 0x9E3779B1u) ^ lseed ^ (lo < lo0 ? him1 : him0));
+                    v = (hsh >> 8) >= thresh ? v * inv_keep : 0.f;
+                }
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, (unsigned)(dco * HT * sizeof(float)), 0);
             }
-        const float bv = bb[co];
-        const size_t base = (((size_t)n * CV1_CO + co) * H + h) * T + t0;
-        const uint64_t idx0 = (((uint64_t)b * CV1_CO + co) * H + h) * T + t0;
-        float out[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float v = acc[k] + bv;
-            v = v > 0.f ? v : 0.f;
-            if (thresh) v = drop_keep(lseed, idx0 + k, thresh) ? v * inv_keep : 0.f;
-            out[k] = v;
-        }
-        if (vec) {
-            *reinterpret_cast<float4*>(y + base) = make_float4(out[0], out[1], out[2], out[3]);
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (t0 + k < T) y[base + k] = out[k];
-        }
     }
 }
 
@@ -183,12 +216,17 @@ size_t cv1_workspace_bytes(const ConvArgs& a) {
 
 int cv1_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, float drop_p, uint32_t seed, int layer,
             hipStream_t st) {
-    const int T4 = (a.T + 3) / 4;
-    const long long total = (long long)a.nbr * a.B * a.H * T4;
+    // the kernel's 32-bit channel offsets (stores and the dropout index): 63 channel planes of H * T floats below 4 GiB
+    if ((long long)(CV1_CO - 1) * a.H * a.T * (long long)sizeof(float) >= (1ll << 32)) {
+        set_error("cv1_fwd: H * T = %lld is beyond the kernel's 32-bit channel offsets", (long long)a.H * a.T);
+        return ZNS_ERR_ARG;
+    }
+    const int tblocks = (a.T + C1_TB - 1) / C1_TB;
+    const long long blocks = (long long)a.nbr * a.B * a.H * tblocks;
     const uint32_t thresh = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
     const float inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
-    hipLaunchKernelGGL(cv1_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.B, a.T, a.H, x, w,
-                       bias, y, thresh, inv_keep, seed, layer, T4, total);
+    hipLaunchKernelGGL(cv1_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a.B, a.T, a.H, x, w, bias, y, thresh,
+                       inv_keep, seed, layer, tblocks);
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
 }
