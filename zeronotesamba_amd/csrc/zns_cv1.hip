@@ -24,6 +24,7 @@ __global__ void __launch_bounds__(256) cv1_fwd_kernel(int B, int T, int H, const
                                                       Ptr2 bias, float* __restrict__ y, uint32_t thresh,
                                                       float inv_keep, uint32_t seed, int layer, int tblocks) {
     __shared__ float sx[CV1_KH * C1_RS];
+    __shared__ float sb[CV1_CO];                   // bias: read per output in the epilogue (LDS, not 32 registers)
     int bid = blockIdx.x;
     const int tb = bid % tblocks; bid /= tblocks;
     const int h = bid % H;
@@ -38,8 +39,9 @@ __global__ void __launch_bounds__(256) cv1_fwd_kernel(int B, int T, int H, const
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int half = lane >> 5, px = lane & 31;
     const float* wb = w.p[br];
-    float a0[C1_STEPS], a1[C1_STEPS], bv[2][16];
+    float a0[C1_STEPS], a1[C1_STEPS];
     int off[C1_STEPS];
+    if (threadIdx.x < CV1_CO) sb[threadIdx.x] = bias.p[br][threadIdx.x];
 #pragma unroll
     for (int st = 0; st < C1_STEPS; ++st) {
         const int kk = 2 * st + half;
@@ -49,10 +51,7 @@ __global__ void __launch_bounds__(256) cv1_fwd_kernel(int B, int T, int H, const
         const int kq = real ? kk : 0;
         off[st] = (kq / CV1_KW) * C1_RS + kq % CV1_KW + px;
     }
-#pragma unroll
-    for (int tl = 0; tl < 2; ++tl)
-#pragma unroll
-        for (int k = 0; k < 16; ++k) bv[tl][k] = bias.p[br][tl * 32 + (k & 3) + 8 * (k >> 2) + 4 * half];
+    const float* sbh = sb + 4 * half;
     const uint32_t lseed = layer_seed(seed, layer, br);
     const size_t HT = (size_t)H * T;
     float* yrow = y + ((size_t)n * CV1_CO * H + h) * T;                    // channel 0 of this (sample, row)
@@ -84,7 +83,7 @@ __global__ void __launch_bounds__(256) cv1_fwd_kernel(int B, int T, int H, const
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int dco = tl * 32 + (k & 3) + 8 * (k >> 2);           // channel = dco + 4 * half
-                float v = (tl ? acc1[k] : acc0[k]) + bv[tl][k];
+                float v = (tl ? acc1[k] : acc0[k]) + sbh[dco];
                 v = v > 0.f ? v : 0.f;
                 if (thresh) {
                     const uint32_t c = (uint32_t)((size_t)dco * HT);             // < 2^32: H * T < 2^26 for any clip
