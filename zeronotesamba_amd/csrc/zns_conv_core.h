@@ -142,7 +142,9 @@ struct CoreArgs {
 // NWL = number of waves that issue the DMA pieces (all of them, or only the youngest wave of every SIMD: see conv_core)
 template <class C>
 struct PatchPlan {
-    static constexpr int NWL = C::HET ? C::NW - C::HET : C::NW;
+    // first loader wave (the 11-wave cv3 backward-data layout measured 2 % slower with four loaders: all of its waves load)
+    static constexpr int LW0 = C::HET ? C::HET : (C::DILMAX > 0 && C::NW >= 8 && C::NW % 4 == 0) ? C::NW - 4 : 0;
+    static constexpr int NWL = C::NW - LW0;
     static constexpr int NPI = (C::PATCH / 64 + NWL - 1) / NWL;       // 4-byte pieces per loader wave (16-byte mode uses a quarter)
     unsigned voff[NPI];
     bool wide;                                                         // 16-byte DMA pieces (wave-uniform)
@@ -365,11 +367,12 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
     const int bbase = C::HET ? lane_h * C::PS + (type_a ? wid : C::HET) * 32 + lane_j + (pw_al - pw)
                              : lane_h * C::PS + (wr * C::RT) * C::PCW + wc * C::CT * 32 + lane_j + (pw_al - pw);
 
-    // Who issues the DMA pieces: in the two-kind layout only the type B waves -- the youngest wave of every SIMD, which
-    // multiplies LAST in a stage (the waves of a SIMD run in age order) and would otherwise wait; the type A waves start
-    // their MFMAs right after the barrier.  Elsewhere every wave issues its share.
-    const bool loader = !C::HET || !type_a;
-    const int lw = C::HET ? wid - C::HET : wid;          // loader wave index
+    // Who issues the DMA pieces: in the frequency-domain layouts of 8 or 12 waves only the last four -- the youngest wave of
+    // every SIMD (in the two-kind layout: the type B waves), which multiplies LAST in a stage (the waves of a SIMD run in
+    // age order) and would otherwise wait; the older waves start their MFMAs right after the barrier.  Elsewhere every
+    // wave issues its share.
+    const bool loader = wid >= PatchPlan<C>::LW0;        // (two-kind layout: exactly the type B waves)
+    const int lw = wid - PatchPlan<C>::LW0;              // loader wave index
     PatchPlan<C> plan;
     if (loader) {
         patch_offsets<C>(plan, xn, h0, w0, T, lw, lane, pw_al,
@@ -398,7 +401,7 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
         constexpr bool TA = decltype(TAC)::value;
         wait_vm0();
         __syncthreads();
-        if ((!C::HET || !TA) && st + 1 < C::NST) {
+        if ((C::HET ? !TA : loader) && st + 1 < C::NST) {
             load_slab<C>(wbase + (size_t)(st + 1) * C::SLAB, slab(st + 1), lw, lane);
             if (r == C::KH - 1) load_patch<C>(plan, xn, cc + 1, T, patch(cc + 1), lw);
         }
