@@ -16,6 +16,7 @@ from zeronotesamba_amd import _lib
 
 
 def cnn(Bbig, T=512, chunk=16):
+    assert Bbig % chunk == 0, "B_big must be a multiple of the chunk (16)"
     model = build()
     x = synth(Bbig, T, 3)
     e_big, _, g_big = run(_lib.ZNS_IMPL_AUTO, model, x, Bbig)
