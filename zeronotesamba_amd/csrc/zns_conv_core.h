@@ -718,9 +718,11 @@ __device__ __forceinline__ void wg_load_tile(const WgArgs& A, int br, int cob, i
     }
 }
 
-// pixel group of a K-tile before which wave group `grp` issues the next tile's DMA pieces: group 0 at the start, the last
-// one no later than three quarters in (its pieces need the rest of the tile to land)
-constexpr int wg_stagger_at(int grp, int gsteps) { return grp == 0 ? 0 : grp == 1 ? gsteps / 2 : (3 * gsteps) / 4; }
+// pixel group of a K-tile before which wave group `grp` issues the next tile's DMA pieces: group 0 at the start, the
+// later groups three quarters into their own multiply (halfway for group 1 measured 1 % slower for cv4, a quarter /
+// half 2-3 % slower: the waves of a SIMD multiply in age order, a later group's early pieces only compete with the
+// older group's reads)
+constexpr int wg_stagger_at(int grp, int gsteps) { return grp == 0 ? 0 : (3 * gsteps) / 4; }
 
 template <class C>
 __global__ void __launch_bounds__(C::NT, C::WPE) wgrad_core(WgArgs A) {
@@ -798,7 +800,7 @@ __global__ void __launch_bounds__(C::NT, C::WPE) wgrad_core(WgArgs A) {
     int cur = 0;
     // One workgroup per CU (8 or 12 waves, 2-3 per SIMD): if every wave issued its share of the next tile's DMA pieces
     // right after the barrier, the matrix pipes would idle for that long in every tile.  The waves of a SIMD take turns
-    // instead: group `wid / 4` issues its pieces after STAG_AT[group] of the tile's CW / 8 pixel groups, while its SIMD
+    // instead: group `wid / 4` issues its pieces at wg_stagger_at(group) of the tile's CW / 8 pixel groups, while its SIMD
     // partners multiply.  (Two 4-wave workgroups per CU: the partner workgroup plays that role.)
     constexpr int NG = C::NW >= 8 ? C::NW / 4 : 1;
     constexpr int GSTEPS = C::CW / 8;
