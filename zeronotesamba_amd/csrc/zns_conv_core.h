@@ -83,7 +83,12 @@ struct ConvCfg {
     static constexpr int PATCH = ((CK * PS + 255) / 256) * 256;  // floats per patch buffer (whole 1-KiB DMA pieces)
     static constexpr int SLAB = CK * KW * COB;                // floats per weight stage
     static constexpr int NCC = CIN / CK, NST = NCC * KH;
-    static constexpr int LDS_BYTES = (2 * SLAB + 2 * PATCH) * 4;
+    static constexpr int OPS_BYTES = (2 * SLAB + 2 * PATCH) * 4;     // the double-buffered operands
+    // two-kind layout: the transposed-store tiles of the epilogue (32 x 36 floats per wave) get LDS of their own when it
+    // fits, so that a workgroup can run several (sample, slot) items back to back with item i's stores beside item
+    // i + 1's first loads and multiplies (see conv_core)
+    static constexpr bool EPI_SEP = HET > 0 && OPS_BYTES + NW * 32 * 36 * 4 <= 160 * 1024;
+    static constexpr int LDS_BYTES = OPS_BYTES + (EPI_SEP ? NW * 32 * 36 * 4 : 0);
     static constexpr int HP = H / POOL;
     static_assert(CIN % CK == 0 && CK % 2 == 0, "CK");
     static_assert(COUT % COB == 0, "COB");
@@ -118,6 +123,7 @@ struct CoreArgs {
     int B, T, N;           // N = nbr*B (x F in the frequency-domain use)
     int ncb;               // column blocks
     int dil, F;            // DILMAX > 0 only: tap spacing, number of frequency slots (weights indexed by (branch, f))
+    int ipw;               // two-kind layout with EPI_SEP: consecutive samples per workgroup (>= 1; the grid shrinks accordingly)
     // EPI 0
     Ptr2 bias;
     float* y;
@@ -332,16 +338,27 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
     const int rb = bid % (C::H / C::RB);
     bid /= (C::H / C::RB);
     const int cob = bid % (C::COUT / C::COB);
-    const int n = bid / (C::COUT / C::COB);
-    const int br = C::DILMAX ? n / (A.B * A.F) : n / A.B;
-    const int widx = C::DILMAX ? br * A.F + n % A.F : br;
+    // several consecutive samples per workgroup (two-kind layout, host guarantees one block per sample then)
+    const int ipw = (C::HET && C::EPI_SEP && A.ipw > 1) ? A.ipw : 1;
+    int n = (bid / (C::COUT / C::COB)) * ipw;
+    const int nitems = ipw > 1 ? (A.N - n < ipw ? A.N - n : ipw) : 1;
+    auto branch_of = [&](int nn) { return C::DILMAX ? nn / (A.B * A.F) : nn / A.B; };
+    const int br = branch_of(n);
     const int dil = C::DILMAX ? A.dil : 1;
     const int pw = C::DILMAX ? (C::KW / 2) * dil : C::PW;
     const int h0 = rb * C::RB, w0 = cb * C::WB;
     const int T = A.T;
 
-    const float* xn = A.x + (size_t)n * C::CIN * C::H * T;
-    const float* wbase = A.wpk + (size_t)widx * C::COUT * C::CIN * C::KH * C::KW + (size_t)cob * C::NST * C::SLAB;
+    auto x_of = [&](int nn) { return A.x + (size_t)nn * C::CIN * C::H * T; };
+    auto w_of = [&](int nn) {
+        const int b2 = branch_of(nn), widx = C::DILMAX ? b2 * A.F + nn % A.F : b2;
+        return A.wpk + (size_t)widx * C::COUT * C::CIN * C::KH * C::KW + (size_t)cob * C::NST * C::SLAB;
+    };
+    const float* xn = x_of(n);
+    const float* wbase = w_of(n);
+    const float* xn_next = xn;          // the item after the current one (ipw > 1)
+    const float* wbase_next = wbase;
+    bool has_next = false;
 
     f32x16 acc[C::MT][C::RT][C::CT];
 #pragma unroll
@@ -401,9 +418,14 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
         constexpr bool TA = decltype(TAC)::value;
         wait_vm0();
         __syncthreads();
-        if ((C::HET ? !TA : loader) && st + 1 < C::NST) {
-            load_slab<C>(wbase + (size_t)(st + 1) * C::SLAB, slab(st + 1), lw, lane);
-            if (r == C::KH - 1) load_patch<C>(plan, xn, cc + 1, T, patch(cc + 1), lw);
+        if (C::HET ? !TA : loader) {
+            if (st + 1 < C::NST) {
+                load_slab<C>(wbase + (size_t)(st + 1) * C::SLAB, slab(st + 1), lw, lane);
+                if (r == C::KH - 1) load_patch<C>(plan, xn, cc + 1, T, patch(cc + 1), lw);
+            } else if (has_next) {          // the next item's first stage (NST is even: buffers 0 are free again)
+                load_slab<C>(wbase_next, slab(0), lw, lane);
+                load_patch<C>(plan, xn_next, 0, T, patch(0), lw);
+            }
         }
         if constexpr (PAR >= 0) {
             if constexpr (C::HET) {
@@ -425,7 +447,7 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
             }
         }
     };
-    auto k_loop = [&](auto TAC) {
+    auto k_stages = [&](auto TAC) {
         if constexpr (C::KH == 1 && C::NCC % 2 == 0) {
             // the frequency-domain use (and cv7 / cv8): stage = channel chunk, two per trip, so that the double
             // buffers' parity is part of the immediates
@@ -440,27 +462,43 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
         }
     };
     if constexpr (C::HET) {
-        if (type_a) k_loop(std::true_type{});      // the barriers inside pair up across the two kinds: same trip count
-        else k_loop(std::false_type{});
-    } else {
-        k_loop(std::true_type{});
-    }
-    if constexpr (C::HET) {
         // tile t of this wave: type A -> (channel tile t, column tile wid); type B -> (channel tile wid-8, column tile 8+t)
         const int pp = A.prev_pool;
-        if (A.xmask == nullptr && pp == 1 && (T & 3) == 0 && (reinterpret_cast<uintptr_t>(A.dx) & 15) == 0) {
-            // plain stores (the frequency-domain use): 16 bytes per lane through store_tile_t
-            __syncthreads();                               // every wave is done with the last stage's operands
-            float* tb = smem + wid * (32 * ETS);
+        const bool plain = A.xmask == nullptr && pp == 1 && (T & 3) == 0 && (reinterpret_cast<uintptr_t>(A.dx) & 15) == 0;
+        // plain stores (the frequency-domain use): 16 bytes per lane through store_tile_t.  With LDS of its own (EPI_SEP) a
+        // wave stores as soon as ITS multiplies are done -- the waves of a SIMD finish one after the other -- and the
+        // workgroup goes on with the next sample: the stores and the next first loads ride beside the other waves' MFMAs
+        // instead of costing a prologue and an epilogue per sample with the matrix pipes idle.
+        auto store_plain = [&](int nn) {
+            if constexpr (!C::EPI_SEP) __syncthreads();            // the tiles reuse the operand buffers
+            float* tb = smem + (C::EPI_SEP ? C::OPS_BYTES / 4 : 0) + wid * (32 * ETS);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if (!type_a && t == 3) break;
                 const int co0 = cob * C::COB + (type_a ? t : het_m0) * 32;
-                store_tile_t(tb, acc[t][0][0], A.dx + ((size_t)n * C::COUT + co0) * T, (size_t)T,
+                store_tile_t(tb, acc[t][0][0], A.dx + ((size_t)nn * C::COUT + co0) * T, (size_t)T,
                              w0 + (type_a ? wid : C::HET + t) * 32, T, lane);
             }
-            return;
-        }
+        };
+        auto items = [&](auto TAC) {
+            for (int it = 0; it < nitems; ++it) {
+                has_next = it + 1 < nitems;
+                if (has_next) { xn_next = x_of(n + 1); wbase_next = w_of(n + 1); }
+                k_stages(TAC);
+                if (!plain) break;                                 // (nitems == 1: the host only batches plain launches)
+                store_plain(n);
+                if (has_next) {
+                    ++n; xn = xn_next; wbase = wbase_next;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) acc[t][0][0][k] = 0.f;
+                }
+            }
+        };
+        if (type_a) items(std::true_type{});       // the barriers inside pair up across the two kinds: same trip counts
+        else items(std::false_type{});
+        if (plain) return;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             if (!type_a && t == 3) break;
@@ -483,6 +521,8 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
             }
         }
         return;
+    } else {
+        k_stages(std::true_type{});
     }
 
     // ------------------------------------------------------------------ epilogue

@@ -848,7 +848,22 @@ static int run_fconv(const ConvArgs& a, const FftGeom& g, Ptr2 w, int transposed
     A.F = FS;
     A.dil = g.NB;
     A.ncb = ceil_div(g.P, C::WB);
-    const long long blocks2 = (long long)A.N * A.ncb * (C::COUT / C::COB);
+    // two-kind layout: consecutive (sample, slot) items per workgroup (one block per item, 16-byte aligned plain stores): the
+    // largest of 4 / 3 / 2 that divides the items and still leaves a workgroup for every CU (ZNS_IPW overrides: tuning)
+    A.ipw = 1;
+    if constexpr (C::HET > 0 && C::EPI_SEP) {
+        static const int ipw_env = [] { const char* e = getenv("ZNS_IPW"); return e ? atoi(e) : 0; }();
+        if (A.ncb == 1 && C::COUT == C::COB && (g.P & 3) == 0 && (reinterpret_cast<uintptr_t>(s_out) & 15) == 0) {
+            if (ipw_env > 0) {
+                A.ipw = ipw_env;
+            } else {
+                for (int cand : {4, 3, 2})
+                    if (A.ipw == 1 && A.N % cand == 0 && A.N / cand >= device_cus()) A.ipw = cand;
+            }
+        }
+    }
+    const long long blocks2 = A.ipw > 1 ? (long long)ceil_div(A.N, A.ipw)
+                                        : (long long)A.N * A.ncb * (C::COUT / C::COB);
     const bool probe = probe_match(probe_kind, a.cin, a.cout, a.kh);
     const int slot = probe ? g_probe.count % g_probe.n : 0;
     if (probe) ZNS_HIP(hipEventRecord(g_probe.start[slot], st));
