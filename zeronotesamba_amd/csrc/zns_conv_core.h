@@ -416,7 +416,9 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
     auto stage = [&](auto PARC, auto TAC, int st, int cc, int r) {
         constexpr int PAR = decltype(PARC)::value;
         constexpr bool TA = decltype(TAC)::value;
-        wait_vm0();
+        // only the waves that issued DMA pieces wait for them (vmcnt also counts a wave's global STORES: a non-loader wave
+        // that has just stored an item's tiles would otherwise sit here until its stores are acknowledged)
+        if (C::HET ? !TA : loader) wait_vm0();
         __syncthreads();
         if (C::HET ? !TA : loader) {
             if (st + 1 < C::NST) {
