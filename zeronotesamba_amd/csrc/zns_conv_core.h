@@ -410,6 +410,10 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
 #pragma unroll
     for (int s = 0; s < C::KW; ++s) asm volatile("" : "+v"(tap[s]));
     constexpr int PBYTES = C::PATCH * 4;
+    // a wave whose column tiles all lie beyond the row (the last column block of cv2: P = 960 = 3 x 256 + 192, the fourth
+    // wave's 64 columns are padding) skips its multiplies -- it still loads and meets the barriers -- and leaves its SIMD's
+    // matrix pipe to the co-resident workgroups
+    const bool idle = !C::HET && w0 + wc * C::CT * 32 >= T;
 
     // one stage of the K loop; PAR >= 0: buffer parity known at compile time (an immediate), -1: run-time parity;
     // TAC: the wave kind of the two-kind layout
@@ -429,6 +433,7 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
                 load_patch<C>(plan, xn_next, 0, T, patch(0), lw);
             }
         }
+        if (idle) return;
         if constexpr (PAR >= 0) {
             if constexpr (C::HET) {
                 f32x16(&hacc)[4] = *reinterpret_cast<f32x16(*)[4]>(&acc[0][0][0]);
