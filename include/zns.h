@@ -177,12 +177,16 @@ int zns_xqt_host_bank(int mode, int* n_fft8, float* fir, size_t fir_floats, doub
 int zns_xqt_f32(const float* wav, int n_clips, int n_samples, int sample_rate, int mode,
                 float* out, void* ws, size_t ws_bytes, void* stream);
 /* The same, one stage at a time (measurement and tests): stages = 1 builds the decimation pyramid in `ws`, 2 applies
- * the filter bank to the pyramid already in `ws`, 3 = both = zns_xqt_f32.  With both stages the default plan is the
- * per-stage launches; OR ZNS_XQT_MARCH into `stages` to run the second implementation instead, one persistent kernel that
- * marches through each clip with both stages side by side (vqt only; less HBM traffic, bit-identical results, not faster:
- * see DESIGN.md section 5). */
+ * the filter bank to the pyramid already in `ws`, 3 = both = zns_xqt_f32.  With both stages the vqt transform runs as ONE
+ * fused launch that keeps the pyramid in LDS (`ws` untouched); OR ZNS_XQT_SEPARATE into `stages` for the per-stage launches
+ * instead (same arithmetic, bit-identical results, four times the HBM traffic: DESIGN.md section 5).  cqt always takes the
+ * per-stage launches. */
 #define ZNS_XQT_SEPARATE 4       /* per-stage launches (decimation chains, then the filter bank) */
-#define ZNS_XQT_MARCH 8          /* the persistent marching kernel (vqt only) */
+#define ZNS_XQT_FUSED 8          /* insist on the fused kernel (error where it does not apply: cqt, ZNS_XQT_EXACT) */
+#define ZNS_XQT_EXACT 16         /* validation implementation of the pyramid: resampy's tap-by-tap float32 rounding of
+                                    float64 products emulated exactly (three half-rate instructions per tap, per-stage
+                                    launches); the default accumulates the same taps in the same order with one float32
+                                    fused multiply-add each */
 int zns_xqt_stages_f32(const float* wav, int n_clips, int n_samples, int sample_rate, int mode,
                        float* out, void* ws, size_t ws_bytes, int stages, void* stream);
 

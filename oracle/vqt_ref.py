@@ -75,26 +75,37 @@ def decimate2_taps() -> Tuple[np.ndarray, np.ndarray]:
     return left.astype(np.float64), right.astype(np.float64)
 
 
-def resample2(y: np.ndarray) -> np.ndarray:
+def resample2(y: np.ndarray, accumulate: str = "resampy") -> np.ndarray:
     """librosa.resample(y, 2, 1, res_type='kaiser_fast', fix=True, scale=True) for float32 y.
 
     resampy accumulates `y[t] += weight * x[...]` into a float32 output array tap by tap (left wing
-    first, then right wing): every partial sum is rounded to float32.  Restated exactly."""
+    first, then right wing): every partial sum is rounded to float32.  Restated exactly (accumulate="resampy").
+
+    Two other arithmetics of the SAME taps in the SAME order, used by the tests to state how far apart equally valid
+    roundings of this sum lie (they are not restatements of the reference):
+      "fma32"   -- taps rounded once to float32, one float32 fused multiply-add per tap (the HIP default path)
+      "float64" -- float64 accumulation, rounded to float32 once at the end (MORE accurate than resampy's own)"""
     y = np.asarray(y, dtype=np.float32)
     n_in = y.shape[0]
     n_out = int(n_in * 0.5)                     # resampy: int(shape * sample_ratio)
     left, right = decimate2_taps()
+    if accumulate == "fma32":                   # a product of two float32 is exact in float64, so this IS the fused rounding
+        left, right = left.astype(np.float32).astype(np.float64), right.astype(np.float32).astype(np.float64)
+    elif accumulate not in ("resampy", "float64"):
+        raise ValueError(accumulate)
+    keep64 = accumulate == "float64"
     t2 = 2 * np.arange(n_out)
-    acc = np.zeros(n_out, dtype=np.float32)
+    acc = np.zeros(n_out, dtype=np.float64 if keep64 else np.float32)
     x64 = y.astype(np.float64)
     for i, w in enumerate(left):                # i_max = min(n + 1, len(left))
         idx = t2 - i
         ok = idx >= 0
-        acc[ok] = (acc[ok].astype(np.float64) + w * x64[idx[ok]]).astype(np.float32)
+        acc[ok] = (acc[ok].astype(np.float64) + w * x64[idx[ok]]).astype(acc.dtype)
     for k, w in enumerate(right):               # k_max = min(n_orig - n - 1, len(right))
         idx = t2 + k + 1
         ok = idx < n_in
-        acc[ok] = (acc[ok].astype(np.float64) + w * x64[idx[ok]]).astype(np.float32)
+        acc[ok] = (acc[ok].astype(np.float64) + w * x64[idx[ok]]).astype(acc.dtype)
+    acc = acc.astype(np.float32)
     n_fix = int(np.ceil(n_in * 0.5))            # librosa: fix_length to ceil(n * ratio)
     if n_fix > n_out:
         acc = np.concatenate([acc, np.zeros(n_fix - n_out, dtype=np.float32)])
@@ -260,8 +271,9 @@ def stft_ones(y: np.ndarray, n_fft: int, hop: int) -> np.ndarray:
     return np.fft.rfft(frames.astype(np.float64), axis=0).astype(np.complex64)
 
 
-def xqt_complex(y: np.ndarray, mode: str = "vqt") -> np.ndarray:
-    """librosa.vqt / librosa.cqt as called by generate_XQT: complex64 [96, 1 + len(y)//256]."""
+def xqt_complex(y: np.ndarray, mode: str = "vqt", accumulate: str = "resampy") -> np.ndarray:
+    """librosa.vqt / librosa.cqt as called by generate_XQT: complex64 [96, 1 + len(y)//256].
+    accumulate: arithmetic of the decimation sums (resample2); anything but "resampy" is a test aid, not the reference."""
     y = np.asarray(y, dtype=np.float32)
     bank, full_lengths = filter_bank(mode)
     resp: List[np.ndarray] = []
@@ -270,7 +282,7 @@ def xqt_complex(y: np.ndarray, mode: str = "vqt") -> np.ndarray:
         if i > 0:
             if len(my_y) < 2:
                 raise ValueError("Input signal length is too short for 8-octave CQT/VQT")
-            my_y = resample2(my_y)
+            my_y = resample2(my_y, accumulate)
         if len(my_y) <= o["n_fft"] // 2:
             raise ValueError("Input signal length is too short for reflect padding")
         D = stft_ones(my_y, o["n_fft"], o["hop"])
@@ -281,15 +293,16 @@ def xqt_complex(y: np.ndarray, mode: str = "vqt") -> np.ndarray:
     for r in resp:                               # __trim_stack: octaves from the top down
         V[end - BPO:end] = r[:, :max_col]
         end -= BPO
-    V /= np.sqrt(full_lengths[:, np.newaxis]).astype(np.float32)
+    # numpy's in-place `complex64 /= float64 array` computes the quotient in complex128 and casts back
+    V[...] = (V.astype(np.complex128) / np.sqrt(full_lengths[:, np.newaxis])).astype(np.complex64)
     return V
 
 
-def generate_XQT(signal: np.ndarray, sample_rate: int, mode: str) -> np.ndarray:
+def generate_XQT(signal: np.ndarray, sample_rate: int, mode: str, accumulate: str = "resampy") -> np.ndarray:
     """input_rep.generate_XQT restated: float32 [96, T]."""
     if mode not in ("vqt", "cqt"):
         raise Exception("Mode can only be vqt or cqt!")
-    V = xqt_complex(signal, mode)
+    V = xqt_complex(signal, mode, accumulate)
     return np.log(np.abs(V) + EPS).astype(np.float32)
 
 

@@ -6,19 +6,29 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from zeronotesamba_amd.processing.input_rep import generate_XQT_batch
 
+STAGES = 3
+
+
 def run(n_clips, iters):
     g = torch.Generator().manual_seed(1234)
     y = (0.1 * torch.randn(n_clips, 160000, generator=g)).cuda()
-    for _ in range(2):
-        out = generate_XQT_batch(y, 16000, "vqt")
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        out = generate_XQT_batch(y, 16000, "vqt")
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / iters
+    res = torch.empty((n_clips, 96, 626), dtype=torch.float32, device="cuda")
+
+    def timed(stages):
+        for _ in range(2):
+            generate_XQT_batch(y, 16000, "vqt", out=res, stages=stages)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            generate_XQT_batch(y, 16000, "vqt", out=res, stages=stages)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters
+
+    dt = timed(STAGES)
+    flags = STAGES & ~3
+    pyr, fir = timed(1 | flags), timed(2 | flags)
     alg = n_clips * (160000 * 4 + 96 * 626 * 4)
-    return {"n_clips": n_clips, "ms": dt * 1e3, "clips_per_s": n_clips / dt, "algorithmic_GBps": alg / dt / 1e9,
+    return {"n_clips": n_clips, "stages": STAGES, "ms": dt * 1e3, "pyramid_ms": pyr * 1e3, "filter_ms": fir * 1e3, "clips_per_s": n_clips / dt, "algorithmic_GBps": alg / dt / 1e9,
             "frac_of_8TBps": alg / dt / 8e12}
 
 def cpu_oracle(n_clips=2):
@@ -36,6 +46,8 @@ def cpu_oracle(n_clips=2):
 
 
 if __name__ == "__main__":
+    if "--stages" in sys.argv:       # e.g. 19 = 3 | ZNS_XQT_EXACT, 11 = 3 | ZNS_XQT_MARCH
+        STAGES = int(sys.argv[sys.argv.index("--stages") + 1])
     sizes = ((32, 50), (64, 30), (128, 20), (256, 10), (512, 10), (4096, 3))
     if "--only" not in sys.argv: sizes = (sizes[0], sizes[4], sizes[5])
     if "--only" in sys.argv:

@@ -64,7 +64,7 @@ SIGNATURES = {
 ZNS_IMPL_AUTO, ZNS_IMPL_NAIVE, ZNS_IMPL_DIRECT = 0, 1, 2
 ZNS_REDUCE_MAX, ZNS_REDUCE_MEAN = 0, 1
 ZNS_MODE_VQT, ZNS_MODE_CQT = 0, 1
-ZNS_XQT_SEPARATE, ZNS_XQT_MARCH = 4, 8
+ZNS_XQT_SEPARATE, ZNS_XQT_FUSED, ZNS_XQT_EXACT = 4, 8, 16
 ZNS_ERR_MODE = -3
 
 

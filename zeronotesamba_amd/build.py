@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 OUT = os.path.join(HERE, "libzns_hip.so")
-SOURCES = ["zns_api.hip", "zns_naive.hip", "zns_small.hip", "zns_cv1.hip", "zns_conv_mfma.hip", "zns_conv_fft.hip", "zns_xqt.hip"]
+SOURCES = ["zns_api.hip", "zns_naive.hip", "zns_small.hip", "zns_cv1.hip", "zns_conv_mfma.hip", "zns_conv_fft.hip", "zns_xqt.hip", "zns_xqt_stream.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17"]
 
 

@@ -22,9 +22,10 @@ _MODES = {"vqt": _lib.ZNS_MODE_VQT, "cqt": _lib.ZNS_MODE_CQT}
 def generate_XQT_batch(signals: torch.Tensor, sample_rate: int, mode: str, out: torch.Tensor = None,
                        stages: int = 3, ws: torch.Tensor = None) -> torch.Tensor:
     """signals: float32 [n_clips, n_samples] on a ROCm device -> float32 [n_clips, 96, 1 + n_samples//256].
-    out: optional preallocated result (steady-state pipelines reuse it).  stages: 3 = the whole transform; 1 / 2 run
-    the decimation pyramid / the filter bank alone on the shared workspace (bench.py times them separately); 3 runs the
-    per-stage launches, 3 | _lib.ZNS_XQT_MARCH the second implementation (one persistent marching kernel; same bits).
+    out: optional preallocated result (steady-state pipelines reuse it).  stages: 3 = the whole transform (vqt: ONE fused
+    launch, the pyramid never leaves LDS; cqt: per-stage launches); 1 / 2 run the decimation pyramid / the filter bank alone on
+    the shared workspace (bench.py times them separately); 3 | _lib.ZNS_XQT_SEPARATE forces the per-stage launches (same bits);
+    | _lib.ZNS_XQT_EXACT selects the validation pyramid that emulates resampy's per-tap rounding bit for bit (slower).
     ws: optional caller-owned uint8 workspace of zns_xqt_workspace_bytes (a pipeline that overlaps two batches on two
     streams gives each its own; the default is one grow-only buffer per device)."""
     if mode not in _MODES:
