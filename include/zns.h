@@ -6,7 +6,9 @@
  * the call signature of generate_XQT() and the torch.nn.Module / autograd protocol
  * of _CNN / DS_CNN / Pretext_CNN / Down_CNN / NTXent.  Each
  * entry point below names the reference lines it replaces.  INTEGRATION.md shows
- * the ctypes binding a maintainer would add on the reference side.
+ * the ctypes binding a maintainer would add on the reference side.  This header is the
+ * PRODUCT surface; the process-global switches and self-tests that the test suite
+ * and bench.py use live in include/zns_test.h (same library) and are not for binding.
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless the parameter says "host";
@@ -47,20 +49,6 @@ extern "C" {
 
 const char* zns_last_error(void);
 int zns_version(void);
-/* TEST / BENCH ONLY -- never call it from a serving or training process.  Selects the kernel family for every later conv
- * fwd/dgrad/wgrad call of the PROCESS (process-wide on purpose: autograd runs backward() on its own thread, which must
- * launch the family a validation test selected on the Python thread).  Returns the previous value. */
-int zns_set_impl(int impl);
-
-/* TEST / BENCH ONLY.  One probe per process: arming while a probe is armed, or disarming from a thread other than the
- * one that armed it, returns ZNS_ERR_ARG.
- * Measurement hook for bench.py: record hipEvents immediately around the MAIN kernel of the next
- * conv launches that match (kind, cin, cout, kh).  kind: 0 forward, 1 backward-data, 2 backward-weights.
- * ev_start/ev_stop: host arrays of n hipEvent_t (created with timing enabled); launch i uses slot
- * i % n.  n == 0 disarms.  Returns the number of matching launches recorded so far via zns_probe_count(). */
-int zns_probe_arm(int kind, int cin, int cout, int kh, void* const* ev_start, void* const* ev_stop, int n);
-int zns_probe_count(void);
-
 /* ------------------------------------------------------------------ conv layers
  * One call = one `nn.Conv2d` (+ the MaxPool2d/ReLU/Dropout that follow it) of
  * _CNN.forward, models.py:37-70, for `nbr` branches at once.
@@ -87,7 +75,7 @@ size_t zns_conv2d_dz_spectrum_bytes(int nbr, int B, int T, int cin, int cout, in
  *   zns_conv2d_pack_f32(geometry, transposed, w, dst, bytes, stream)
  * and passes `wpk = dst` to zns_conv2d_fwd_f32 (transposed = 0) / zns_conv2d_dgrad_f32 (transposed = 1).  `wpk` is valid
  * for every call whose geometry reports the SAME layout_id (the id depends on the layer, on the tile variant the
- * dispatcher picks from T, and on zns_set_impl) -- not only for the T it was packed at. */
+ * dispatcher picks from T, and on the kernel family a test harness may have selected) -- not only for the T it was packed at. */
 size_t zns_conv2d_packed_bytes(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, int transposed,
                                int* layout_id);
 int zns_conv2d_pack_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, int transposed,
@@ -168,12 +156,14 @@ int zns_adam_multi_f32(const void* table, int n_tensors, size_t max_n, float lr,
 /* ------------------------------------------------------------------ generate_XQT (input_rep.py:11-57)
  * wav: [n_clips, n_samples] fp32 @16 kHz; out: [n_clips, 96, 1 + n_samples/256] = log(|XQT| + 1e-9).
  * mode: ZNS_MODE_VQT / ZNS_MODE_CQT, anything else -> ZNS_ERR_MODE.
- * The filter bank (host, float64) is built once per (mode) and cached on the device. */
+ * The filter bank (host, float64) is built once per (mode) and cached on the device.
+ * sample_rate: the reference's signature carries it (input_rep.py:11) and every reference caller passes 16000
+ * (sample_script.py:28, pretext.py:143-147, config.yaml); this library is built for that rate only -- the octave plan
+ * (hop 256 >> i, n_fft per octave, the 2:1 decimation count, the fused kernel's LDS geometry) is a compile-time table of
+ * 16 kHz -- and any other value returns ZNS_ERR_ARG ("only sample_rate=16000 is built") instead of a silently different
+ * transform.  A deliberate narrowing of the signature, not of any call the reference makes. */
 size_t zns_xqt_workspace_bytes(int n_clips, int n_samples, int mode);
 int zns_xqt_frames(int n_samples);
-/* HOST-only helper (no GPU touched): the folded per-octave FIR bank the kernel applies, as interleaved
- * re/im floats [octave][12][n_fft[octave]], and the 32+31 decimation taps.  Used by the CPU tests. */
-int zns_xqt_host_bank(int mode, int* n_fft8, float* fir, size_t fir_floats, double* taps63);
 int zns_xqt_f32(const float* wav, int n_clips, int n_samples, int sample_rate, int mode,
                 float* out, void* ws, size_t ws_bytes, void* stream);
 /* The same, one stage at a time (measurement and tests): stages = 1 builds the decimation pyramid in `ws`, 2 applies
@@ -189,11 +179,6 @@ int zns_xqt_f32(const float* wav, int n_clips, int n_samples, int sample_rate, i
                                     fused multiply-add each */
 int zns_xqt_stages_f32(const float* wav, int n_clips, int n_samples, int sample_rate, int mode,
                        float* out, void* ws, size_t ws_bytes, int stages, void* stream);
-
-/* TEST ONLY.  The pyramid divides by float32(sqrt(0.5)) as `(float)((double)x * (1 / c))`; this runs that against the
- * float32 division over ALL 2^32 float32 bit patterns.  mismatches (device, 8 bytes) receives the count of differing
- * results, first_bad_bits (device, 4 bytes) the smallest differing input's bits (0xFFFFFFFF: none). */
-int zns_selftest_div_sqrt_half(unsigned long long* mismatches, unsigned* first_bad_bits, void* stream);
 
 /* ------------------------------------------------------------------ shift batching (pretext.py:285-292,308-321)
  * bank: [n_bank, 2, 96, bank_T]; for item i of the batch: out[i] = bank[clip[i], :, :, start[i]:start[i]+T]

@@ -1,5 +1,5 @@
-"""CPU: the C-ABI library loads and exports every symbol include/zns.h declares; host-only entry points
-behave (no compute calls: there is no GPU here)."""
+"""CPU: the C-ABI library loads and exports every symbol include/zns.h (product) and include/zns_test.h (test / bench only)
+declare; host-only entry points behave (no compute calls: there is no GPU here)."""
 import ctypes as C
 import os
 import re
@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def header_symbols():
-    src = open(os.path.join(ROOT, "include", "zns.h")).read()
+def header_symbols(name="zns.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(zns_[a-z0-9_]+)\s*\(", src)))
 
@@ -24,6 +24,13 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, s), f"libzns_hip.so does not export {s}"
     # and the ctypes table binds exactly the header's surface
     assert sorted(_lib.SIGNATURES.keys()) == syms
+    # the test / bench surface is a separate header and a separate table; nothing of it leaks into the product header
+    tsyms = header_symbols("zns_test.h")
+    assert sorted(_lib.TEST_SIGNATURES.keys()) == tsyms and not set(tsyms) & set(syms)
+    for s in tsyms:
+        assert hasattr(L, s), f"libzns_hip.so does not export {s}"
+    for word in ("zns_set_impl", "zns_probe", "selftest", "host_bank", "debug"):
+        assert word not in open(os.path.join(ROOT, "include", "zns.h")).read()
 
 
 def test_host_only_entry_points():

@@ -16,13 +16,10 @@ _lib: Optional[C.CDLL] = None
 c_fp = C.c_void_p          # device pointers travel as integers
 c_pp = C.POINTER(C.c_void_p)
 
-# name -> (restype, argtypes); mirrors include/zns.h one to one
+# name -> (restype, argtypes); mirrors include/zns.h (the product surface) one to one
 SIGNATURES = {
     "zns_last_error": (C.c_char_p, []),
     "zns_version": (C.c_int, []),
-    "zns_set_impl": (C.c_int, [C.c_int]),
-    "zns_probe_arm": (C.c_int, [C.c_int] * 4 + [c_pp, c_pp, C.c_int]),
-    "zns_probe_count": (C.c_int, []),
     "zns_conv2d_workspace_bytes": (C.c_size_t, [C.c_int] * 8),
     "zns_conv2d_spectrum_bytes": (C.c_size_t, [C.c_int] * 8),
     "zns_conv2d_dz_spectrum_bytes": (C.c_size_t, [C.c_int] * 8),
@@ -49,16 +46,24 @@ SIGNATURES = {
                                      C.c_float, c_fp]),
     "zns_xqt_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "zns_xqt_frames": (C.c_int, [C.c_int]),
-    "zns_xqt_host_bank": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_size_t,
-                                    C.POINTER(C.c_double)]),
     "zns_xqt_f32": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp, C.c_size_t, c_fp]),
     "zns_xqt_stages_f32": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_fp, c_fp, C.c_size_t, C.c_int, c_fp]),
-    "zns_selftest_div_sqrt_half": (C.c_int, [c_fp, c_fp, c_fp]),
     "zns_shift_gather_f32": (C.c_int, [c_fp, C.c_int, c_fp, c_fp, C.c_int, C.c_int, c_fp, c_fp]),
     "zns_stem_mix_f32": (C.c_int, [c_fp, C.c_int, C.c_longlong, c_fp, c_fp]),
     "zns_stage_crops_f32": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_int, c_fp, c_fp]),
     "zns_rms_frames": (C.c_int, [C.c_int]),
     "zns_rms_gate_f32": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, C.c_int, c_fp, c_fp, c_fp, c_fp]),
+}
+
+# include/zns_test.h: test / bench only (kernel-family switch, measurement probe, self-tests, host tables)
+TEST_SIGNATURES = {
+    "zns_set_impl": (C.c_int, [C.c_int]),
+    "zns_probe_arm": (C.c_int, [C.c_int] * 4 + [c_pp, c_pp, C.c_int]),
+    "zns_probe_count": (C.c_int, []),
+    "zns_xqt_host_bank": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_size_t,
+                                    C.POINTER(C.c_double)]),
+    "zns_selftest_div_sqrt_half": (C.c_int, [c_fp, c_fp, c_fp]),
+    "zns_xqt_debug_stamps": (C.c_int, [C.POINTER(C.c_ulonglong), C.c_size_t]),
 }
 
 ZNS_IMPL_AUTO, ZNS_IMPL_NAIVE, ZNS_IMPL_DIRECT = 0, 1, 2
@@ -77,7 +82,7 @@ def lib() -> C.CDLL:
                 f"zeronotesamba_amd: {LIB_PATH} not found. The MI355X kernels are the only implementation; "
                 "build them with `python -m zeronotesamba_amd.build` (needs hipcc).")
         handle = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(TEST_SIGNATURES.items()):
             fn = getattr(handle, name)  # AttributeError if the .so lacks a declared entry point
             fn.restype = res
             fn.argtypes = args

@@ -27,6 +27,7 @@ def _hipcc() -> str:
 def _newest_header() -> float:
     hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hs.append(os.path.join(HERE, "..", "include", "zns.h"))
+    hs.append(os.path.join(HERE, "..", "include", "zns_test.h"))
     return max(os.path.getmtime(h) for h in hs)
 
 

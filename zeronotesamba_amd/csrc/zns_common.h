@@ -5,6 +5,7 @@
 #include <stdio.h>
 
 #include "../../include/zns.h"
+#include "../../include/zns_test.h"
 
 namespace zns {
 

@@ -51,6 +51,7 @@ __device__ __forceinline__ float xqt_log_magnitude(float re, float im) {
 
 // The fused kernel (zns_xqt_stream.hip): both stages in ONE launch, pyramid levels never leave LDS.  vqt bank only.
 bool xqt_stream_supported(const Bank* b, int n_clips, int n_samples);
+unsigned long long* xqt_stream_stamps();   // tuning aid, see ZNS_XQT_STAMPS
 int xqt_stream_launch(const Bank* b, const float* wav, int n_clips, int n_samples, float* out, hipStream_t st);
 
 }  // namespace zns

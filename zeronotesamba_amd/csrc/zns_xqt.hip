@@ -710,6 +710,14 @@ int zns_xqt_host_bank(int mode, int* n_fft8, float* fir, size_t fir_floats, doub
     return ZNS_OK;
 }
 
+int zns_xqt_debug_stamps(unsigned long long* host_out, size_t n) {
+    unsigned long long* d = xqt_stream_stamps();
+    ZNS_CHECK_ARG(d != nullptr && host_out != nullptr && n <= 32 * 12 * 8, "xqt_debug_stamps: no stamped launch (set ZNS_XQT_STAMPS)");
+    ZNS_HIP(hipDeviceSynchronize());
+    ZNS_HIP(hipMemcpy(host_out, d, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return ZNS_OK;
+}
+
 int zns_xqt_frames(int n_samples) { return n_samples < 0 ? 0 : 1 + n_samples / XQ_HOP; }
 
 size_t zns_xqt_workspace_bytes(int n_clips, int n_samples, int mode) {
@@ -779,7 +787,9 @@ int zns_xqt_stages_f32(const float* wav, int n_clips, int n_samples, int sample_
     if (stages == 3 && !(plan_flags & ZNS_XQT_SEPARATE)) {
         const bool can = !exact && xqt_stream_supported(b, n_clips, n_samples);
         ZNS_CHECK_ARG(can || !(plan_flags & ZNS_XQT_FUSED), "xqt: the fused kernel is built for the vqt bank and the default pyramid arithmetic");
-        if (can) return xqt_stream_launch(b, wav, n_clips, n_samples, out, st);
+        // a handful of clips cannot fill the fused kernel's pipeline (its nine steps of ramp weigh as much as the work:
+        // 36 us against 28 us for one clip, equal at 32, 2.80 against 3.40 ms at 4096; tools/bench_xqt_sizes.py)
+        if (can && ((plan_flags & ZNS_XQT_FUSED) || n_clips >= 16)) return xqt_stream_launch(b, wav, n_clips, n_samples, out, st);
     }
     // decimation pyramid: levels 1..7, grouped into chains (one launch each).  Default plan: the two big levels on
     // their own (no recomputed halo where 3/4 of the taps are), then chains of two and three (the small levels' launches

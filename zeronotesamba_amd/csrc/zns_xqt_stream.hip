@@ -37,6 +37,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace sq {
 
+#define SQ_STAMP(P, s, k)                                                                                   \
+    do {                                                                                                    \
+        if ((P).stamps && blockIdx.x == 0 && (s) >= 64 && (s) < 96 && (threadIdx.x & 63) == 0)             \
+            (P).stamps[(((s) - 64) * 12 + (threadIdx.x >> 6)) * 8 + (k)] = __builtin_amdgcn_s_memtime();   \
+    } while (0)
+
 constexpr int S0 = 4096;                  // level-0 samples per step = 16 frames
 constexpr int NPYR = 512, NTHR = 768;     // 8 pyramid waves + 4 filter-bank waves
 constexpr int LAG = XQ_OCT + 1;           // steps behind the loader at which the last role (octave 7's tile) runs, plus one
@@ -199,6 +205,7 @@ struct Args {
     int nout[XQ_OCT];            // resampy's output count of level j >= 1: len[j - 1] / 2
     int nitems, nck, chs, W, K, G;   // items = n_clips * nck; chunks per clip; steps per chunk; warm-up steps; steps per item; workgroups
     int dbg;                     // tuning aid (ZNS_XQT_DBG): 1 skip the taps, 2 skip the multiplies, 4 skip the staging, 8 skip the stores
+    unsigned long long* stamps;  // tuning aid (ZNS_XQT_STAMPS): [step 64..95][wave 0..11][8] s_memtime stamps of workgroup 0
 };
 
 // item `it` of workgroup b -> (clip, chunk)
@@ -254,6 +261,7 @@ __device__ __forceinline__ void pyramid_role(const Args& P, float* __restrict__ 
     const TapPairs& W = P.taps;
     for (int s = 0; s < steps; ++s) {
         const int par = s & 1;
+        SQ_STAMP(P, s, 0);
         // ---- level 0: the step's 8 samples of this thread, global -> registers (stored at the end of the step)
         float4 fa = make_float4(0.f, 0.f, 0.f, 0.f), fb = fa;
         if (it0 < nmine) {
@@ -273,6 +281,7 @@ __device__ __forceinline__ void pyramid_role(const Args& P, float* __restrict__ 
                 if (idx + 7 >= 0 && idx + 7 < P.n) fb.w = x[idx + 7];
             }
         }
+        SQ_STAMP(P, s, 1);
         // ---- own level: eight outputs from the window the level below filled in the previous step
         if (!idle) {
             float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -294,6 +303,7 @@ __device__ __forceinline__ void pyramid_role(const Args& P, float* __restrict__ 
             *reinterpret_cast<float4*>(lds + dst_a0 + flip) = make_float4(v[0], v[1], v[2], v[3]);
             *reinterpret_cast<float4*>(lds + dst_a1 + flip) = make_float4(v[4], v[5], v[6], v[7]);
         }
+        SQ_STAMP(P, s, 2);
         // ---- slide: the last HS samples of a window open the next one
         if (slider)
             *reinterpret_cast<float4*>(lds + sl_dst + (par ? 0 : sl_4pl)) = *reinterpret_cast<const float4*>(lds + sl_src + (par ? sl_4pl : 0));
@@ -302,7 +312,9 @@ __device__ __forceinline__ void pyramid_role(const Args& P, float* __restrict__ 
         *reinterpret_cast<float4*>(lds + ld_a1 + (par ? 0 : 4 * PL_(0))) = fb;
         if (++u0 == P.K) { u0 = 0; ++it0; item_of(P, b, it0, clip0, ck0); }
         if (++uj == P.K) { uj = 0; ++itj; item_of(P, b, itj, clipj, ckj); }
+        SQ_STAMP(P, s, 3);
         __syncthreads();
+        SQ_STAMP(P, s, 4);
     }
 }
 
@@ -505,6 +517,7 @@ __device__ __forceinline__ void filter_role(const Args& P, float* __restrict__ l
     if (!(P.dbg & 64)) __builtin_amdgcn_s_setprio(3);
     for (int s = 0; s < steps; ++s) {
         const int par = s & 1;
+        SQ_STAMP(P, s, 0);
         OB.begin(P, nmine); OS.begin(P, nmine);
         if constexpr (WV == 0) OE.begin(P, nmine);
         const bool stage = !(P.dbg & 4);
@@ -516,12 +529,16 @@ __device__ __forceinline__ void filter_role(const Args& P, float* __restrict__ l
         if (stage && OB.tile) { if (OB.edge) stage_edge<WV>(P.wav + (long long)OB.clip * P.n, P.len[WV], OB.worig(P), OB.Ff, lds, stgB, par, lane); else OB.stage_store(stgB, lane, vb); }
         if (stage && OS.tile) { if (OS.edge) stage_edge<S1>(P.wav + (long long)OS.clip * P.n, P.len[S1], OS.worig(P), OS.Ff, lds, stgS, par, lane); else OS.stage_store(stgS, lane, vs); }
         if constexpr (WV == 0) { if (stage && OE.tile) { if (OE.edge) stage_edge<4>(P.wav + (long long)OE.clip * P.n, P.len[4], OE.worig(P), OE.Ff, lds, stgE, par, lane); else OE.stage_store(stgE, lane, ve); } }
+        SQ_STAMP(P, s, 1);
         if (OB.tile) octave_mma<WV, 3>(P, OB, stgB, lane, a0, a1);
+        SQ_STAMP(P, s, 2);
         if (OS.tile) octave_mma<S1, S1_RTM>(P, OS, stgS, lane, c0, c1);
         if constexpr (WV == 0) { if (OE.tile) octave_mma<4, 2>(P, OE, stgE, lane, e1, e1); }
         OB.advance(P, b); OS.advance(P, b);
         if constexpr (WV == 0) OE.advance(P, b);
+        SQ_STAMP(P, s, 3);
         __syncthreads();
+        SQ_STAMP(P, s, 4);
     }
 }
 
@@ -542,6 +559,9 @@ __global__ void __launch_bounds__(NTHR) xqt_stream_kernel(Args P) {
 }
 
 }  // namespace sq
+
+static unsigned long long* g_last_stamps = nullptr;
+unsigned long long* xqt_stream_stamps() { return g_last_stamps; }
 
 bool xqt_stream_supported(const Bank* b, int n_clips, int n_samples) {
     if (n_clips < 1 || n_samples < 1) return false;
@@ -583,6 +603,13 @@ int xqt_stream_launch(const Bank* b, const float* wav, int n_clips, int n_sample
     A.nitems = n_clips * A.nck;
     A.G = std::min(A.nitems, ncu);
     if (const char* e = getenv("ZNS_XQT_DBG")) A.dbg = atoi(e);
+    static unsigned long long* g_stamps = nullptr;
+    if (getenv("ZNS_XQT_STAMPS")) {      // tuning aid: cycle stamps of workgroup 0, dumped by zns_xqt_debug_stamps
+        if (!g_stamps) ZNS_HIP(hipMalloc(&g_stamps, 32 * 12 * 8 * sizeof(unsigned long long)));
+        ZNS_HIP(hipMemsetAsync(g_stamps, 0, 32 * 12 * 8 * sizeof(unsigned long long), st));
+        A.stamps = g_stamps;
+        g_last_stamps = g_stamps;
+    }
     const size_t lds = (size_t)LDS_FLOATS * sizeof(float);
     static bool lds_set[ZNS_MAX_DEVICES] = {};
     if (!lds_set[current_device_slot()]) {
