@@ -228,15 +228,24 @@ XQT_SAMPLES = 160000                     # 10 s at 16 kHz (BASELINE configs[1])
 XQT_BYTES_PER_CLIP = XQT_SAMPLES * 4 + 96 * (1 + XQT_SAMPLES // 256) * 4      # 640 KB in + 240 KB out
 XQT_TAPS_PER_CLIP = 63 * sum(-(-XQT_SAMPLES // (1 << i)) for i in range(1, 8))   # decimation: 63 taps per pyramid sample
 XQT_FILTER_FLOP_PER_CLIP = 2 * 2 * 12 * (1 + XQT_SAMPLES // 256) * (128 * 4 + 64 + 32 + 32 + 16)   # complex FIR bank, VQT
-F64_TAP_CEILING = 12.7e12                # taps/s/chip: fma_f64 + cvt_f32_f64 + cvt_f64_f32 = 12.35 cycles per wave (tools/ubench_f64.hip)
+F64_TAP_CEILING = 12.7e12                # taps/s/chip of the EXACT pyramid: fma_f64 + cvt_f32_f64 + cvt_f64_f32 = 12.35 cycles per wave (tools/ubench_f64.hip)
+VALU_CYCLES_PER_INSTR = 4.2              # any vector instruction, one wave64 per SIMD (tools/ubench_valu.hip: v_fma_f32 75 TFLOP/s, v_pk_fma_f32 147)
 
 
 def measure_xqt(dev, cpu: bool) -> dict:
-    """BASELINE configs[1]: generate_XQT on 32 resident clips and on a bandwidth-saturating 4096; the two
-    stages are also timed alone.  Bounds: the whole transform against the 8 TB/s HBM roofline (algorithmic bytes), the
-    bit-exact decimation against its float64 instruction-issue ceiling, the filter bank against the fp32 FMA peak."""
+    """BASELINE configs[1]: generate_XQT on 32 resident clips and on a bandwidth-saturating 4096.  The default
+    plan for vqt is ONE fused launch (pyramid in LDS, HBM traffic = clip in + spectrogram out); beside it the per-stage
+    launches of the same arithmetic (pyramid / filter bank timed alone) and the exact validation pyramid.  Bounds: the whole
+    transform against the 8 TB/s HBM roofline (algorithmic bytes), and against the fp32 instruction-issue floor of its own
+    arithmetic -- the vector FMAs of the pyramid and the matrix-pipe FMAs of the filter bank share one issue port per SIMD."""
+    from zeronotesamba_amd import _lib
     from zeronotesamba_amd.processing.input_rep import generate_XQT_batch
     out = {}
+    # packed taps: 67 vector instructions per output pair (59 v_pk_fma_f32 + 8 v_fma_f32) instead of 126; filter bank: one
+    # v_mfma_f32_16x16x4_f32 (32 cycles) per 4 taps x 16 frames x 16 rows, two row tiles for the 24 real rows of an octave
+    issue_cycles_per_clip = (XQT_TAPS_PER_CLIP / 63.0 / 2.0) * 67 / 64.0 * VALU_CYCLES_PER_INSTR \
+        + (1 + XQT_SAMPLES // 256) / 16.0 * 2 * (128 * 4 + 64 + 32 + 32 + 16) / 4.0 * 32.0
+    issue_floor_s_per_clip = issue_cycles_per_clip / (1024 * 2.4e9)          # 1024 SIMDs at the 2.4 GHz peak clock
     for n_clips, iters in ((32, 50), (4096, 3)):
         g = torch.Generator(device="cpu").manual_seed(1234)
         y = (0.1 * torch.randn((min(n_clips, 64), XQT_SAMPLES), generator=g)).to(dev)
@@ -244,16 +253,24 @@ def measure_xqt(dev, cpu: bool) -> dict:
             y = y.repeat(n_clips // y.shape[0], 1).contiguous()
         res = torch.empty((n_clips, 96, 1 + XQT_SAMPLES // 256), dtype=torch.float32, device=dev)
         ms = _timed(lambda: generate_XQT_batch(y, SR, "vqt", out=res), iters)
+        ms_sep = _timed(lambda: generate_XQT_batch(y, SR, "vqt", out=res, stages=3 | _lib.ZNS_XQT_SEPARATE), iters)
         ms_pyr = _timed(lambda: generate_XQT_batch(y, SR, "vqt", out=res, stages=1), iters)
         ms_fir = _timed(lambda: generate_XQT_batch(y, SR, "vqt", out=res, stages=2), iters)
+        ms_exact = _timed(lambda: generate_XQT_batch(y, SR, "vqt", out=res, stages=3 | _lib.ZNS_XQT_EXACT), iters)
+        ms_pyr_exact = _timed(lambda: generate_XQT_batch(y, SR, "vqt", out=res, stages=1 | _lib.ZNS_XQT_EXACT), iters)
         gbps = n_clips * XQT_BYTES_PER_CLIP / (ms * 1e-3) / 1e9
         out[f"clips_{n_clips}"] = {
-            "ms": ms, "clips_per_s": n_clips / (ms * 1e-3), "algorithmic_GBps": gbps, "frac_of_8TBps": gbps / 8000.0,
-            "pyramid_ms": ms_pyr, "pyramid_frac_of_f64_issue_ceiling": n_clips * XQT_TAPS_PER_CLIP / (ms_pyr * 1e-3) / F64_TAP_CEILING,
-            "filter_ms": ms_fir, "filter_frac_of_fp32_peak": n_clips * XQT_FILTER_FLOP_PER_CLIP / (ms_fir * 1e-3) / (FP32_MFMA_PEAK_TFLOPS * 1e12)}
+            "ms": ms, "plan": "fused (one launch, pyramid in LDS)", "clips_per_s": n_clips / (ms * 1e-3),
+            "algorithmic_GBps": gbps, "frac_of_8TBps": gbps / 8000.0,
+            "frac_of_fp32_issue_floor": n_clips * issue_floor_s_per_clip / (ms * 1e-3),
+            "per_stage_launches_ms": ms_sep, "pyramid_ms": ms_pyr, "filter_ms": ms_fir,
+            "filter_frac_of_fp32_peak": n_clips * XQT_FILTER_FLOP_PER_CLIP / (ms_fir * 1e-3) / (FP32_MFMA_PEAK_TFLOPS * 1e12),
+            "exact_pyramid_plan_ms": ms_exact, "exact_pyramid_ms": ms_pyr_exact,
+            "exact_pyramid_frac_of_f64_issue_ceiling": n_clips * XQT_TAPS_PER_CLIP / (ms_pyr_exact * 1e-3) / F64_TAP_CEILING}
         del y, res
-    out["bound"] = ("hbm by SURVEY 8(d); in practice the bit-exact resampy accumulation (one float32 rounding per tap = 3 "
-                    "half-rate float64-path instructions) bounds the pyramid at 12.7e12 taps/s, see DESIGN.md section 5")
+    out["bound"] = ("hbm by SURVEY 8(d) (0.88 MB algorithmic per clip); the fused kernel moves just those bytes (profiles/r04_xqt_*) and "
+                    "is bound by fp32 instruction issue: 1.0e7 decimation taps + 1.3e7 matrix-pipe multiply-adds per clip on one issue "
+                    "port per SIMD (issue floor = frac_of_fp32_issue_floor), see DESIGN.md section 5")
     if cpu:
         import numpy as np
         from oracle import vqt_ref

@@ -48,10 +48,12 @@ def test_bench_line_has_every_contract_field():
     assert c["module_path_ms_per_step"] > 0 and 0.8 < c["module_path_vs_fused"] < 3.0
     for n in ("clips_32", "clips_4096"):
         x = c["xqt"][n]
-        for k in ("ms", "clips_per_s", "algorithmic_GBps", "frac_of_8TBps", "pyramid_ms", "filter_ms",
-                  "pyramid_frac_of_f64_issue_ceiling", "filter_frac_of_fp32_peak"):
+        for k in ("ms", "clips_per_s", "algorithmic_GBps", "frac_of_8TBps", "frac_of_fp32_issue_floor", "per_stage_launches_ms",
+                  "pyramid_ms", "filter_ms", "filter_frac_of_fp32_peak", "exact_pyramid_plan_ms", "exact_pyramid_ms",
+                  "exact_pyramid_frac_of_f64_issue_ceiling"):
             assert x[k] > 0, (n, k)
-        assert x["pyramid_frac_of_f64_issue_ceiling"] < 1.0 and x["frac_of_8TBps"] < 1.0
+        assert x["exact_pyramid_frac_of_f64_issue_ceiling"] < 1.0 and x["frac_of_8TBps"] < 1.0 and x["frac_of_fp32_issue_floor"] < 1.0
+        assert x["ms"] < x["exact_pyramid_plan_ms"]                    # the default arithmetic is the faster one
     ft = c["finetune"]
     assert ft["frames"] == 1876 and ft["ms_per_step"] > 0 and 0 < ft["executed_frac_of_fp32_mfma_peak"] < 1.0
     # the benchmarked embeddings are not collapsed to a constant (cosines would read 1.0000)

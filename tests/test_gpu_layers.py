@@ -71,6 +71,60 @@ def test_conv_layer_ragged_and_long(li, T, nbr, B):
     check_conv_layer(li, "auto", T, nbr=nbr, B=B)
 
 
+@pytest.mark.parametrize("li,impl", CASES)
+def test_conv_layer_hands_non_finite_values_on_as_aten_does(li, impl):
+    """models.py:37-70 on the reference's side is conv2d -> max_pool2d -> relu -> dropout of ATen: a NaN in a pooling window
+    wins the max, relu(NaN) = NaN, relu(+inf) = +inf, and a DROPPED NaN is still a NaN (x * 0).  A run that has diverged
+    must look diverged here too -- the fused epilogues once compared with `v > best` / `v > 0 ? v : 0` / `keep ? v : 0`,
+    which swallow a NaN.  One NaN in sample 0 and one +inf in sample 1:
+      * every element the reference makes NaN is NaN on the device, every +-inf is that inf (or NaN), eval and train mode;
+      * what the device makes non-finite BEYOND the reference is confined to the poisoned sample and to the 64-sample
+        overlap-save windows around the poisoned column (the frequency-domain kernels transform a window at a time: an inf
+        becomes a NaN there and both reach the whole window; the one-thread-per-output kernels add nothing at all);
+      * everything else is finite and equal to 1e-4."""
+    _lib, _ops = _mods()
+    L = _lib.lib()
+    name, cin, cout, kh, kw, pool = _ops.LAYERS[li]
+    H, T, nbr, B = _ops.H_IN[li], 200, 1, 2
+    dev = torch.device("cuda:0")
+    x = rnd(50 + li, (nbr * B, cin, H, T))
+    w = [rnd(60 + li, (cout, cin, kh, kw), 1.0 / np.sqrt(cin * kh * kw))]
+    b = [rnd(70 + li, (cout,), 0.1)]
+    t_nan, t_inf = 77, 130
+    x[0, cin // 2, H // 2, t_nan] = float("nan")
+    x[1, cin - 1, H // 3, t_inf] = float("inf")
+    z = F.conv2d(x, w[0], b[0], padding=(kh // 2, kw // 2))
+    y_ref = F.relu(F.max_pool2d(z, (pool, 1)) if pool > 1 else z)
+    assert torch.isnan(y_ref[0]).any() and torch.isinf(y_ref[1]).any() and not torch.isnan(y_ref[1]).any()
+    prev = L.zns_set_impl({"naive": _lib.ZNS_IMPL_NAIVE, "direct": _lib.ZNS_IMPL_DIRECT, "auto": _lib.ZNS_IMPL_AUTO}[impl])
+    try:
+        ws = _ops.workspace(_ops.conv_workspace_bytes(nbr, B, T), dev)
+        xd, wd, bd = x.to(dev), [w[0].to(dev)], [b[0].to(dev)]
+        seed = 99
+        keep = torch.from_numpy(dropout_ref.keep_mask(dropout_ref.layer_seed(seed, li, 0), tuple(y_ref.shape), 0.1).astype(np.float32))
+        for drop_p, ref in ((0.0, y_ref), (0.1, y_ref * keep * np.float32(1.0 / 0.9))):
+            y = _ops.conv_fwd(li, nbr, B, T, xd, wd, bd, drop_p, seed, True, ws)[0].cpu()
+            rn, ri = torch.isnan(ref), torch.isinf(ref)
+            assert rn.any() and ri.any()
+            assert bool(torch.isnan(y)[rn].all()), f"{name} {impl} p={drop_p}: a NaN was swallowed"
+            assert bool(((y == ref) | torch.isnan(y))[ri].all()), f"{name} {impl} p={drop_p}: an inf was swallowed"
+            extra = ~torch.isfinite(y) & torch.isfinite(ref)
+            if impl == "naive":
+                assert not extra.any()
+            else:
+                # 64-sample windows advance by V = 65 - kw: a poisoned column touches at most two of them
+                near = torch.zeros_like(extra)
+                near[0, :, :, max(0, t_nan - 64 - kw):t_nan + 64 + kw] = True
+                near[1, :, :, max(0, t_inf - 64 - kw):t_inf + 64 + kw] = True
+                assert not (extra & ~near).any(), f"{name} {impl}: non-finite values outside the poisoned windows"
+            ok = torch.isfinite(y) & torch.isfinite(ref)
+            assert ok.float().mean().item() > 0.25
+            scale = ref[ok].abs().max().item()
+            assert (y[ok] - ref[ok]).abs().max().item() <= 1e-4 * scale
+    finally:
+        L.zns_set_impl(prev)
+
+
 def check_conv_layer(li, impl, T, nbr, B):
     _lib, _ops = _mods()
     L = _lib.lib()
@@ -229,6 +283,24 @@ def test_head_and_down():
                                                da.data_ptr(), dp.data_ptr(), _ops.stream_ptr()), "down_bwd")
         close(da, ac.grad, tol=1e-7, what="down da")
         close(dp, pc.grad, tol=1e-7, what="down dp")
+    # torch.max hands a NaN of either side on (models.py:147-148), BCELoss keeps a NaN output a NaN loss (epochs.py:61)
+    an, pn = a.clone(), p.clone()
+    an[1, 2] = float("nan")
+    pn[2, 3] = float("nan")
+    and_, pnd = an.to(dev), pn.to(dev)
+    out = torch.empty_like(and_)
+    _lib.check(_lib.lib().zns_down_fwd_f32(and_.data_ptr(), pnd.data_ptr(), an.numel(), _lib.ZNS_REDUCE_MAX,
+                                           out.data_ptr(), _ops.stream_ptr()), "down_fwd")
+    ref = torch.maximum(an, pn)
+    assert torch.equal(torch.isnan(out.cpu()), torch.isnan(ref)) and int(torch.isnan(ref).sum()) == 2
+    from zeronotesamba_amd.epochs import bce_loss
+    o = torch.rand(1, 50).clamp(0.01, 0.99)
+    tgt = (torch.rand(1, 50) > 0.5).float()
+    assert abs(bce_loss(o.to(dev), tgt.to(dev)).item() - F.binary_cross_entropy(o, tgt).item()) < 1e-6
+    o[0, 7] = float("nan")
+    with pytest.raises(RuntimeError):                     # ATen refuses a NaN input outright (its range check fails on it) ...
+        F.binary_cross_entropy(o, tgt)
+    assert torch.isnan(bce_loss(o.to(dev), tgt.to(dev)))  # ... here the loss reads NaN; what must not happen is a finite loss
 
 
 def test_unsupported_and_bad_arguments_fail_loudly():

@@ -47,6 +47,31 @@ def test_trainer_step_equals_module_path():
     assert d.max().item() <= lr * 1.001 and d.mean().item() > 0.5 * lr
 
 
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_a_non_finite_input_gives_a_non_finite_loss(bad):
+    """pretext.py:486-492: the reference's loop would print a NaN loss the step after its input (or a weight) went bad.
+    One poisoned spectrogram element, train mode (a dropped NaN must stay a NaN): the loss of the module path and of the
+    fused trainer are NaN, every gradient tensor is poisoned, and the oracle agrees."""
+    from oracle import step_ref
+    from zeronotesamba_amd.models.loss_functions import NTXent
+    from zeronotesamba_amd.pretext import PretextTrainer
+    B, T, tau = 4, 64, 0.25
+    batch = cnn_ref.synth_vqt(200, (B, 2, 96, T))
+    batch[1, 0, 40, 33] = bad
+    ma, mb = make_model(), make_model()
+    ma.train()
+    a, p = ma(batch[:, 0:1].to(DEV), batch[:, 1:2].to(DEV))
+    loss, _, _ = NTXent(B, tau)(a, p)
+    assert torch.isnan(loss)
+    tr = PretextTrainer(mb, batch_len=B, temperature=tau, lr=1e-4, train=True)
+    out3 = tr.step(tr.stack_inputs(batch), update=False)
+    assert torch.isnan(out3[0])
+    assert not torch.isfinite(tr.flat_g).all()
+    op = step_ref.OracleParams(cnn_ref.synth_state_dict(5, 2.0), 1e-4)
+    rl = step_ref.pretext_step(op, batch, B, tau)[0]
+    assert np.isnan(rl)
+
+
 def test_fused_adam_matches_torch_adam():
     """zns_adam_step_f32 against torch.optim.Adam on well-conditioned gradients (|g| >> eps)."""
     from zeronotesamba_amd.optim import Adam

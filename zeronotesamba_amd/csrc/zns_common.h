@@ -59,6 +59,15 @@ __device__ inline bool drop_keep(uint32_t seed, uint64_t idx, uint32_t thresh) {
     return (hash_u32(seed, idx) >> 8) >= thresh;
 }
 
+// Non-finite values go through the fused epilogues as they go through ATen's ops (models.py:37-70 on the reference's side):
+//   max_pool2d   a NaN in the window wins (`val > max || isnan(val)`; the LAST NaN's position is the arg-max)
+//   relu         relu(NaN) = NaN (threshold keeps what is not <= 0), relu(+inf) = +inf
+//   dropout      input * mask / (1 - p): a dropped NaN or inf is NaN (x * 0), not 0
+// A diverged run must look diverged here too: a plain `v > best` / `v > 0 ? v : 0` / `keep ? v : 0` would swallow the NaN.
+__device__ __forceinline__ bool pool_takes(float v, float best) { return v > best || v != v; }
+__device__ __forceinline__ float relu_nan(float v) { return v <= 0.f ? 0.f : v; }
+__device__ __forceinline__ float drop_apply(bool keep, float v, float inv_keep) { return keep ? v * inv_keep : v * 0.f; }
+
 // Per-branch pointer pack passed by value to kernels (nbr <= 2).
 struct Ptr2 {
     const float* p[2];

@@ -555,14 +555,14 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
 #pragma unroll
                         for (int a = 1; a < C::POOL; ++a) {
                             const float v = acc[m][g * C::POOL + a][ct][k];
-                            if (v > best) { best = v; am = a; }
+                            if (pool_takes(v, best)) { best = v; am = a; }
                         }
                         float v = best + bias[co];
-                        v = v > 0.f ? v : 0.f;
+                        v = relu_nan(v);
                         const size_t o = (((size_t)n * C::COUT + co) * C::HP + hp) * T + col;
                         if (A.thresh) {
                             const uint64_t idx = (((uint64_t)b_in_br * C::COUT + co) * C::HP + hp) * T + col;
-                            v = drop_keep(lseed, idx, A.thresh) ? v * A.inv_keep : 0.f;
+                            v = drop_apply(drop_keep(lseed, idx, A.thresh), v, A.inv_keep);
                         }
                         A.y[o] = v;
                         if (C::POOL > 1 && A.argmax) A.argmax[o] = (uint8_t)am;

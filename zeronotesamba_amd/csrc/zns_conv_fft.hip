@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__
                         int av = 0;
                         for (int a = 1; a < pool; ++a) {
                             const float t = sp[a * NB * VS];
-                            if (t > rv) { rv = t; av = a; }
+                            if (pool_takes(t, rv)) { rv = t; av = a; }
                         }
                         r[u][k] = rv;
                         am[u][k] = av;
@@ -275,10 +275,10 @@ __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__
                     float t = r[u][k];
                     if (MODE == 1) {
                         t += mk[u][k];
-                        t = t > 0.f ? t : 0.f;
+                        t = relu_nan(t);
                         if (E.thresh) {
                             const uint64_t idx = ((uint64_t)bb * C * Hq + Rqv[u][k]) * T + colv[u][k];
-                            t = drop_keep(lseed, idx, E.thresh) ? t * E.inv_keep : 0.f;
+                            t = drop_apply(drop_keep(lseed, idx, E.thresh), t, E.inv_keep);
                         }
                         amw |= (uint32_t)am[u][k] << (8 * k);
                     } else if (MODE == 2) {
@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__
                         const vec_t t = ld_stage<VW, ROW>(sp + a * NB * VS);
 #pragma unroll
                         for (int k = 0; k < VW; ++k)
-                            if (t[k] > r[u][k]) { r[u][k] = t[k]; amw[u] = (amw[u] & ~(0xffu << (8 * k))) | ((uint32_t)a << (8 * k)); }
+                            if (pool_takes(t[k], r[u][k])) { r[u][k] = t[k]; amw[u] = (amw[u] & ~(0xffu << (8 * k))) | ((uint32_t)a << (8 * k)); }
                     }
                     if (MODE == 1) {
                         const float bvv = E.bias.p[br][fastdiv(Rq[u], Hq, E.mHq)];
@@ -360,10 +360,10 @@ __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__
 #pragma unroll
                     for (int k = 0; k < VW; ++k) {
                         float t = rr[k] + mk[u][k];
-                        t = t > 0.f ? t : 0.f;
+                        t = relu_nan(t);
                         if (E.thresh) {
                             const uint64_t idx = ((uint64_t)bb * C * Hq + Rq[u]) * T + col[u] + k;
-                            t = drop_keep(lseed, idx, E.thresh) ? t * E.inv_keep : 0.f;
+                            t = drop_apply(drop_keep(lseed, idx, E.thresh), t, E.inv_keep);
                         }
                         rr[k] = t;
                     }
@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__
                 r[u] = sp[0];
                 for (int a = 1; a < pool; ++a) {
                     const float t = sp[a * NB * VS];
-                    if (t > r[u]) { r[u] = t; am[u] = a; }             // first maximum wins, as ATen's max_pool2d
+                    if (pool_takes(t, r[u])) { r[u] = t; am[u] = a; }   // first maximum wins, a NaN wins over all: ATen's max_pool2d
                 }
                 if (MODE == 1) mk[u] = E.bias.p[br][fastdiv(Rq[u], Hq, E.mHq)];
                 if (MODE == 2) {
@@ -433,10 +433,10 @@ __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__
                 out[o[u]] = rr;
             } else if (MODE == 1) {
                 rr += mk[u];
-                rr = rr > 0.f ? rr : 0.f;
+                rr = relu_nan(rr);
                 if (E.thresh) {
                     const uint64_t idx = ((uint64_t)bb * C * Hq + Rq[u]) * T + col[u];
-                    rr = drop_keep(lseed, idx, E.thresh) ? rr * E.inv_keep : 0.f;
+                    rr = drop_apply(drop_keep(lseed, idx, E.thresh), rr, E.inv_keep);
                 }
                 out[o[u]] = rr;
                 if (E.argmax && pool > 1) E.argmax[o[u]] = (uint8_t)am[u];

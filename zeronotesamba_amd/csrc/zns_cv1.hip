@@ -84,12 +84,12 @@ __global__ void __launch_bounds__(256) cv1_fwd_kernel(int B, int T, int H, const
             for (int k = 0; k < 16; ++k) {
                 const int dco = tl * 32 + (k & 3) + 8 * (k >> 2);           // channel = dco + 4 * half
                 float v = (tl ? acc1[k] : acc0[k]) + sbh[dco];
-                v = v > 0.f ? v : 0.f;
+                v = relu_nan(v);
                 if (thresh) {
                     const uint32_t c = (uint32_t)((size_t)dco * HT);             // < 2^32: H * T < 2^26 for any clip
                     const uint32_t lo = lo0 + c;
                     const uint32_t hsh = lowbias32((lo0m + c * 0x9E3779B1u) ^ lseed ^ (lo < lo0 ? him1 : him0));
-                    v = (hsh >> 8) >= thresh ? v * inv_keep : 0.f;
+                    v = drop_apply((hsh >> 8) >= thresh, v, inv_keep);
                 }
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, voff, (unsigned)(dco * HT * sizeof(float)), 0);
             }

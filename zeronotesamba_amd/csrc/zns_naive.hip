@@ -42,16 +42,16 @@ __global__ void naive_conv_fwd(int nbr, int B, int T, int cin, int cout, int kh,
                     }
                 }
             }
-            if (acc > best) {
+            if (pool_takes(acc, best)) {
                 best = acc;
                 besta = a;
             }
         }
         float v = best + bias.p[br][co];
-        v = v > 0.f ? v : 0.f;
+        v = relu_nan(v);
         if (thresh) {
             const uint64_t idx = (uint64_t)(o - (long long)br * per_branch);
-            v = drop_keep(layer_seed(seed, layer, br), idx, thresh) ? v * inv_keep : 0.f;
+            v = drop_apply(drop_keep(layer_seed(seed, layer, br), idx, thresh), v, inv_keep);
         }
         y[o] = v;
         if (argmax) argmax[o] = (uint8_t)besta;

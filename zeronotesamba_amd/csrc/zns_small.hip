@@ -101,7 +101,8 @@ __global__ void down_fwd_kernel(const float* __restrict__ a, const float* __rest
                                 float* __restrict__ out) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float x = a[i], y = p[i];
-        out[i] = reduction == ZNS_REDUCE_MEAN ? (x + y) / 2.0f : fmaxf(x, y);
+        // torch.max(a, b) hands a NaN of either side on (fmaxf would drop it)
+        out[i] = reduction == ZNS_REDUCE_MEAN ? (x + y) / 2.0f : (x != x ? x : (y != y ? y : fmaxf(x, y)));
     }
 }
 __global__ void down_bwd_kernel(const float* __restrict__ a, const float* __restrict__ p,
@@ -251,7 +252,10 @@ __global__ void __launch_bounds__(1024) bce_kernel(const float* __restrict__ o, 
     float s = 0.f;
     for (size_t i = threadIdx.x; i < n; i += 1024) {
         const float x = o[i], y = t[i];
-        const float l1 = fmaxf(logf(x), -100.f), l0 = fmaxf(logf(1.f - x), -100.f);  // ATen clamps the logs at -100
+        // ATen clamps the logs at -100; a clamp keeps a NaN (fmaxf would turn a NaN output into a finite loss)
+        float l1 = logf(x), l0 = logf(1.f - x);
+        l1 = l1 < -100.f ? -100.f : l1;
+        l0 = l0 < -100.f ? -100.f : l0;
         s -= y * l1 + (1.f - y) * l0;
         if (dout) dout[i] = grad_scale * (x - y) / fmaxf((1.f - x) * x, 1e-12f) / (float)n;
     }
