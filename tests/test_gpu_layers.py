@@ -61,7 +61,10 @@ RAGGED = [(1, 31, 2, 1), (1, 32, 1, 3), (2, 33, 2, 1), (3, 45, 1, 1), (4, 97, 2,
           (3, 3751, 1, 1), (1, 2501, 1, 1),
           # every residue of T mod 4 through the flat 16-byte epilogue of the inverse transform (one-segment rows), with
           # and without pooling / unpooling, and an odd two-segment row (T = 627: the scalar epilogue)
-          (1, 34, 1, 2), (2, 39, 2, 1), (3, 66, 2, 1), (4, 47, 1, 1), (5, 121, 2, 1), (2, 627, 1, 1)]
+          (1, 34, 1, 2), (2, 39, 2, 1), (3, 66, 2, 1), (4, 47, 1, 1), (5, 121, 2, 1), (2, 627, 1, 1),
+          # cv1 alone (its own matrix-pipe kernels: a K = 34 GEMM per image row forward, taps as a GEMM over pixels backward):
+          # every residue of T mod 4, rows shorter than one 32-column group, the reference's 313-frame crop, odd batches
+          (0, 31, 1, 1), (0, 34, 2, 3), (0, 39, 1, 3), (0, 313, 2, 1), (0, 627, 1, 1), (0, 33, 1, 1)]
 
 
 @pytest.mark.parametrize("li,T,nbr,B", RAGGED)

@@ -72,6 +72,35 @@ def test_a_non_finite_input_gives_a_non_finite_loss(bad):
     assert np.isnan(rl)
 
 
+def test_gradient_accumulation_through_step_accumulate():
+    """step(update=False) leaves ONE batch's gradient in flat_g; accumulate=True adds the next one in place (the
+    backward-weights kernels accumulate), apply_update(1 / k) then applies the mean -- and every micro-batch of one
+    accumulation draws its own dropout masks (the seed folds in a micro-batch counter that the update resets)."""
+    from zeronotesamba_amd.pretext import PretextTrainer
+    B, T = 4, 64
+    tr = PretextTrainer(make_model(), batch_len=B, lr=1e-4, train=False)
+    x1 = tr.stack_inputs(cnn_ref.synth_vqt(201, (B, 2, 96, T)))
+    x2 = tr.stack_inputs(cnn_ref.synth_vqt(202, (B, 2, 96, T)))
+    tr.step(x1, update=False)
+    g1 = tr.flat_g.clone()
+    tr.step(x2, update=False)
+    g2 = tr.flat_g.clone()
+    assert not torch.equal(g1, g2)
+    tr.step(x1, update=False)
+    tr.step(x2, update=False, accumulate=True)
+    ref = g1 + g2
+    assert (tr.flat_g - ref).abs().max().item() <= 1e-6 * ref.abs().max().item()
+    before, steps = tr.flat_p.clone(), tr.step_count
+    tr.apply_update(0.5)
+    assert tr.step_count == steps + 1 and tr.micro_count == 0 and not torch.equal(before, tr.flat_p)
+    # dropout on: two micro-batches of the SAME input inside one accumulation must not share their masks
+    tt = PretextTrainer(make_model(), batch_len=B, lr=1e-4, train=True, seed=11)
+    tt.step(x1, update=False)
+    ga = tt.flat_g.clone()
+    tt.step(x1, update=False)
+    assert not torch.equal(ga, tt.flat_g)
+
+
 def test_fused_adam_matches_torch_adam():
     """zns_adam_step_f32 against torch.optim.Adam on well-conditioned gradients (|g| >> eps)."""
     from zeronotesamba_amd.optim import Adam

@@ -153,7 +153,7 @@ def packed_weights(li: int, transposed: bool, nbr: int, B: int, T: int, w: Seque
     """The kernel-order operand of layer li's weights, or None (the C side then packs into the call's workspace).
 
     Only inside a `frozen_weights()` block is an operand cached: on the first branch's weight Parameter, keyed by the
-    library's layout id (layer, tile variant, kernel family) and the tensors' addresses, validated by their autograd
+    library's layout id (layer, tile variant, kernel family), the launch stream and the tensors' addresses, validated by their autograd
     version counters (a second guard: an optimizer step inside the block still rebuilds), dropped when the outermost
     block exits."""
     if not weights_frozen():
@@ -165,7 +165,9 @@ def packed_weights(li: int, transposed: bool, nbr: int, B: int, T: int, w: Seque
         nbytes = L.zns_conv2d_packed_bytes(nbr, B, T, cin, cout, kh, kw, H_IN[li], int(transposed), _lib.C.byref(lid))
         if lid.value == 0:
             return None
-        key = (int(transposed), lid.value, nbr) + tuple(t.data_ptr() for t in w)
+        # the operand is built by a kernel on the CURRENT stream: a forward on another stream must not be handed a buffer
+        # that may still be being written there (and must not return it to that stream's allocator pool while reading it)
+        key = (int(transposed), lid.value, nbr, stream_ptr(w[0].device)) + tuple(t.data_ptr() for t in w)
         sig = tuple(t._version for t in w)
         with _frozen.lock:
             if _frozen.touched is None:        # the scope closed on another thread meanwhile

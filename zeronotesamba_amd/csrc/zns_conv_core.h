@@ -91,6 +91,9 @@ struct ConvCfg {
     static constexpr int LDS_BYTES = OPS_BYTES + (EPI_SEP ? NW * 32 * 36 * 4 : 0);
     static constexpr int HP = H / POOL;
     static_assert(CIN % CK == 0 && CK % 2 == 0, "CK");
+    // several items per workgroup (EPI_SEP): the next item's first slab and patch are requested into buffers 0 during the
+    // current item's LAST stage, which must therefore read buffers 1: an even number of stages, one kernel row
+    static_assert(!EPI_SEP || (KH == 1 && NCC % 2 == 0), "items per workgroup need an even stage count");
     static_assert(COUT % COB == 0, "COB");
     static_assert(H % RB == 0, "RB");
     static_assert(SLAB % 256 == 0, "slab must be whole 1-KiB DMA pieces");

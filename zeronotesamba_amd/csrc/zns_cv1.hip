@@ -222,8 +222,10 @@ size_t cv1_workspace_bytes(const ConvArgs& a) {
 
 int cv1_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, float drop_p, uint32_t seed, int layer,
             hipStream_t st) {
-    // the kernel's 32-bit channel offsets (stores and the dropout index): 63 channel planes of H * T floats below 4 GiB
-    if ((long long)(CV1_CO - 1) * a.H * a.T * (long long)sizeof(float) >= (1ll << 32)) {
+    // the kernel's 32-bit channel offsets (stores and the dropout index), and its masked lanes: a lane past the row's end
+    // carries voffset 0x80000000 and relies on the buffer's range check (voffset + instruction offset >= num_records; the
+    // scalar offset is not part of it), so num_records -- the 63 channel planes plus one row -- must stay below 2 GiB
+    if (((long long)(CV1_CO - 1) * a.H * a.T + a.T) * (long long)sizeof(float) >= (1ll << 31)) {
         set_error("cv1_fwd: H * T = %lld is beyond the kernel's 32-bit channel offsets", (long long)a.H * a.T);
         return ZNS_ERR_ARG;
     }

@@ -224,7 +224,7 @@ class PretextTrainer:
         self.model = model
         self.batch_len, self.temperature = batch_len, temperature
         self.lr, self.betas, self.eps = lr, betas, eps
-        self.seed, self.step_count = seed, 0
+        self.seed, self.step_count, self.micro_count = seed, 0, 0
         self.train_mode = train
         self.pg = process_group
         self.world = 1
@@ -328,7 +328,10 @@ class PretextTrainer:
         return p
 
     def _next_seed(self) -> int:
-        s = (self.seed * 0x9E3779B1 + self.step_count * 0x85EBCA77 + self.rank * 0xC2B2AE3D + 1) & 0x7FFFFFFF
+        # step_count only advances with an update: the micro-batch counter keeps the dropout masks of the batches of one
+        # gradient accumulation apart
+        s = (self.seed * 0x9E3779B1 + self.step_count * 0x85EBCA77 + self.rank * 0xC2B2AE3D
+             + self.micro_count * 0x27D4EB2F + 1) & 0x7FFFFFFF
         return s
 
     def stack_inputs(self, batch: torch.Tensor) -> torch.Tensor:
@@ -337,18 +340,25 @@ class PretextTrainer:
         b = batch.to(dev, non_blocking=True)
         return b.transpose(0, 1).reshape(2 * b.shape[0], 1, b.shape[2], b.shape[3]).contiguous()
 
-    def step(self, x: torch.Tensor, update: bool = True) -> torch.Tensor:
-        """x: [2B,1,96,T] branch-major.  Returns a device tensor (loss, mean pos cos, mean neg cos); no host sync."""
+    def step(self, x: torch.Tensor, update: bool = True, accumulate: bool = False) -> torch.Tensor:
+        """x: [2B,1,96,T] branch-major.  Returns a device tensor (loss, mean pos cos, mean neg cos); no host sync.
+        update=False leaves the gradient of this batch in `flat_g` and the parameters alone; accumulate=True ADDS this
+        batch's gradient to what `flat_g` holds (the backward-weights kernels accumulate in place) -- gradient
+        accumulation over k batches is `step(x1, update=False)`, `step(x2, update=False, accumulate=True)`, ...,
+        `apply_update(1 / k)`.  Every micro-batch draws its own dropout masks.  Not with data_parallel (the bucketed
+        all-reduce sums what is in the buffer: reduce once, after the last micro-batch)."""
         self._check_flat()
+        if accumulate and self.reducer is not None:
+            raise RuntimeError("PretextTrainer.step(accumulate=True) is not supported with data_parallel=True")
         B = x.shape[0] // 2
         T = x.shape[-1]
         if B > self.batch_len:
             raise IndexError(f"PretextTrainer: {B} rows > batch_len={self.batch_len}")
         _ops.same_device(self.flat_p, (x,), "PretextTrainer.step")
         with _ops.on_device(x):
-            return self._step(x, B, T, update)
+            return self._step(x, B, T, update, accumulate)
 
-    def _step(self, x: torch.Tensor, B: int, T: int, update: bool) -> torch.Tensor:
+    def _step(self, x: torch.Tensor, B: int, T: int, update: bool, accumulate: bool = False) -> torch.Tensor:
         drop_p = self._drop_p()
         inv_keep = 1.0 / (1.0 - drop_p)
         seed = self._next_seed()
@@ -358,8 +368,9 @@ class PretextTrainer:
         demb = torch.empty_like(emb)
         _ops.ntxent(emb[:B], emb[B:], B, T, self.batch_len, self.temperature, out3, demb[:B], demb[B:])
         hook = self.reducer.layer_done if self.reducer is not None else None
-        _ops.stack_backward(x, self.P, Bs, acts, argm, emb, demb, None, inv_keep, self.G, accumulate=False,
+        _ops.stack_backward(x, self.P, Bs, acts, argm, emb, demb, None, inv_keep, self.G, accumulate=accumulate,
                             after_layer=hook)
+        self.micro_count += 1
         if self.reducer is not None:
             self.reducer.wait()
         if update:
@@ -368,8 +379,9 @@ class PretextTrainer:
 
     def apply_update(self, grad_scale: float = 1.0) -> None:
         """ONE fused Adam launch over the flat buffers with the gradient read as `grad_scale * flat_g` (1/world after a
-        summing all-reduce; 1/k after accumulating k batches with step(update=False))."""
+        summing all-reduce; 1/k after accumulating k batches with step(update=False, accumulate=True))."""
         self.step_count += 1
+        self.micro_count = 0
         dev = self.flat_p.device
         with _ops.on_device(self.flat_p):
             rc = _lib.lib().zns_adam_step_f32(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(),
@@ -530,8 +542,13 @@ def fill_memory_bank(all_stems: Dict[str, Dict[str, Any]], fps: Sequence[str], y
     row_len = 3 + MAX_OTHER
     chunk = max(1, min(chunk, len(fps)))
 
+    resident = {}                 # file index -> (others, drums) on the device: a file speculated behind a miss is not uploaded twice
+    dev = None
+
     def signals(i):
         """(other stems in dict order, drums) of file i as device float32 vectors (no copy when they already are)."""
+        if i in resident:
+            return resident[i]
         stems = all_stems[fps[i].strip()]
         others, drums = [], None
         for name, sig in stems.items():
@@ -552,6 +569,9 @@ def fill_memory_bank(all_stems: Dict[str, Dict[str, Any]], fps: Sequence[str], y
             raise ValueError("all stems must have the same length")
         if m - n - 1 < 0:
             raise ValueError(f"signal of {m} samples is shorter than a {length} s clip")
+        # the crop table hands raw pointers to zns_stage_crops_f32, which cannot tell whose memory they are
+        _ops.same_device(drums if dev is None else staged, others + [drums], f"stems of {fps[i].strip()!r}")
+        resident[i] = (others, drums)
         return others, drums
 
     dev = signals(0)[1].device
@@ -604,11 +624,14 @@ def fill_memory_bank(all_stems: Dict[str, Dict[str, Any]], fps: Sequence[str], y
             for q in range(j):
                 r.randint(0, rows[q][1].numel() - n - 1)
             others, drums = rows[j][0], rows[j][1]
-            anchor, _ = mix_stems(all_stems[fps[pos].strip()])
+            # the same float32 sum in the same (dict) order, from the vectors already on the device
+            anchor, _ = mix_stems({**{f"other{q}": o for q, o in enumerate(others)}, "drums": drums})
             st = select_clip(anchor, drums, length, lower_p, upper_p, r)
             keep.append(stage(pos - base, [(others, drums, st)]))
             pos += 1
             break
+        for i in [i for i in resident if i < pos]:                         # files whose crop is final; speculated ones stay for the next group
+            del resident[i]
         if pos - base == chunk or pos == len(fps):                         # the chunk's rows are final: transform them
             k = pos - base
             generate_XQT_batch(staged[:k].reshape(2 * k, n), 16000, mode, out=bank[base:pos].view(2 * k, 96, T))
