@@ -437,6 +437,7 @@ def test_two_rank_trainer_replicas_stay_identical_and_equal_the_accumulated_step
         o0 = tr.step(tr.stack_inputs(W.rank_batch(st, 0)), update=False)
         g0 = tr.flat_g.clone()
         tr.rank = 1
+        tr.micro_count = 0                                         # rank 1's first (only) micro-batch of this step, not rank 0's second
         o1 = tr.step(tr.stack_inputs(W.rank_batch(st, 1)), update=False)
         tr.flat_g += g0
         tr.rank = 0
