@@ -332,6 +332,28 @@ def measure_finetune(dev, cpu: bool, iters: int = 10) -> dict:
     return out
 
 
+def cu_masked_stream(dev, reserve_per_xcd: int = 1):
+    """A HIP stream whose kernels may not use `reserve_per_xcd` CUs of every XCD (hipExtStreamCreateWithCUMask: one bit per
+    CU, 32-bit words; on MI355X bits [32 i, 32 i + 32) are XCD i's CUs, tools/exp_cu_mask.py), wrapped so that torch -- and
+    with it every launch of the trainer, which enqueues on torch's current stream -- can use it."""
+    import ctypes
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    words = [0xFFFFFFFF] * ((ncu + 31) // 32)
+    for i in range(len(words)):
+        for k in range(reserve_per_xcd):
+            words[i] &= ~(1 << (31 - k))
+    if ncu % 32:
+        words[-1] &= (1 << (ncu % 32)) - 1
+    hip = ctypes.CDLL("libamdhip64.so")
+    s = ctypes.c_void_p()
+    arr = (ctypes.c_uint32 * len(words))(*words)
+    with torch.cuda.device(dev):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(s), ctypes.c_uint32(len(words)), arr)
+    if rc != 0 or not s.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+    return torch.cuda.ExternalStream(s.value, device=dev)
+
+
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without torchrun's environment: start N FRESH rank processes (this file, with
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would) and relay rank 0's JSON line.
@@ -349,55 +371,72 @@ def self_launch(n: int) -> int:
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    import collections
+    import threading
+    procs, tails, readers = [], [], []
+    found = []
+
+    def pump(r, stream, is_out):
+        """Pass a rank's output through to our stderr as it comes and keep its last 50 lines (rank 0's stdout: the one
+        JSON line is held back for our stdout)."""
+        for raw in stream:
+            if is_out and raw.startswith("{") and not found:
+                found.append(raw.rstrip("\n"))
+                continue
+            tails[r].append(raw.rstrip("\n"))
+            sys.stderr.write(raw if raw.startswith("[rank") else f"[rank {r}] {raw}")
+            sys.stderr.flush()
+
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL's intra-node transport on this pool
         env.setdefault("OMP_NUM_THREADS", "1")                # as torch.distributed.run sets it
-        # rank 0's stdout carries the one JSON line; the other ranks' stdout is diagnostics only
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True if r == 0 else None))
-    import threading
-    rc = 0
-    found = []
-
-    def relay():                                               # ends when rank 0 closes its stdout (exit)
-        for raw in procs[0].stdout:
-            if raw.startswith("{") and not found:
-                found.append(raw.rstrip("\n"))
-            else:
-                sys.stderr.write(raw)
-
-    th = threading.Thread(target=relay, daemon=True)
-    th.start()
+        # rank 0's stdout carries the one JSON line; everything else a rank prints is diagnostics
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, bufsize=1)
+        procs.append(p)
+        tails.append(collections.deque(maxlen=50))
+        for stream, is_out in ((p.stdout, r == 0), (p.stderr, False)):
+            th = threading.Thread(target=pump, args=(r, stream, is_out), daemon=True)
+            th.start()
+            readers.append(th)
+    rc, failed, timed_out = 0, None, False
     try:
-        deadline = time.time() + float(os.environ.get("ZNS_BENCH_LAUNCH_TIMEOUT", "3600"))
+        # the driver gives the whole command 1800 s: fail well inside that, with the ranks' own words on stderr
+        deadline = time.time() + float(os.environ.get("ZNS_BENCH_LAUNCH_TIMEOUT", "900"))
         pending = list(procs)
         while pending and time.time() < deadline:
             for p in list(pending):
                 c = p.poll()
                 if c is not None:
                     pending.remove(p)
-                    rc = rc or c
+                    if c and not rc:
+                        rc, failed = c, procs.index(p)
             if rc:                                             # one rank died: its peers would wait in a collective
                 break
             time.sleep(0.05)
-        if pending:
-            rc = rc or 1
+        if pending and not rc:
+            rc, timed_out = 1, True
     finally:
         for p in procs:
             if p.poll() is None:
                 p.kill()
                 p.wait()
-    th.join(timeout=10)
+    for th in readers:
+        th.join(timeout=10)
     line = found[0] if found else None
     if rc == 0 and line is None:
         rc = 1
     if rc == 0:
         print(line, flush=True)
     else:
-        print(f"bench.py: a rank exited with code {rc}; no result line", file=sys.stderr)
+        why = "timed out (ZNS_BENCH_LAUNCH_TIMEOUT)" if timed_out else f"rank {failed} exited with code {rc}" if failed is not None else "no result line from rank 0"
+        print(f"bench.py: {why}; the last lines of every rank follow (each rank reports its phases as it passes them)", file=sys.stderr)
+        for r in range(n):
+            print(f"---- rank {r}: last {len(tails[r])} lines ----", file=sys.stderr)
+            for t in tails[r]:
+                print(f"    {t}", file=sys.stderr)
     return rc
 
 
@@ -476,9 +515,19 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
 
+    t_start = time.time()
+    env_rank = int(os.environ.get("RANK", "0"))
+
+    def phase(what):
+        """One stderr line per phase and rank: when a multi-GPU run hangs or dies, the launcher's relay of each rank's
+        last lines shows which rank stopped where."""
+        if args.gpus > 1:
+            print(f"[rank {env_rank}] {what} ok (+{time.time() - t_start:.1f} s)", file=sys.stderr, flush=True)
+
     from zeronotesamba_amd import _lib
     from zeronotesamba_amd.distributed import init_from_env
     from zeronotesamba_amd.pretext import PretextTrainer
+    phase("import")
 
     # ZNS_BENCH_BACKEND=gloo is a functional dry run of the N > 1 path on a box with fewer GPUs than ranks (ranks then
     # share devices and gradients travel through the host): never a performance number.
@@ -486,7 +535,9 @@ def main():
     if backend != "nccl":
         local_dev = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_dev)
-    rank, world, local = init_from_env(backend if args.gpus > 1 else None)
+    rank, world, local = init_from_env(backend if args.gpus > 1 else None,
+                                       timeout_s=float(os.environ.get("ZNS_BENCH_PG_TIMEOUT", "300")))
+    phase(f"init_process_group({backend})")
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if backend != "nccl":
@@ -495,7 +546,12 @@ def main():
     dev = torch.device("cuda", local)
 
     model = build_model(dev)
+    phase("model built")
+    if os.environ.get("ZNS_BENCH_FAIL_RANK") == str(env_rank):      # test hook: a rank that dies before its first collective
+        print(f"[rank {env_rank}] ZNS_BENCH_FAIL_RANK: exiting with code 7", file=sys.stderr, flush=True)
+        sys.exit(7)
     trainer = PretextTrainer(model, batch_len=B, temperature=TAU, lr=LR, seed=1234, train=True, data_parallel=world > 1)
+    phase("trainer built, rank 0's parameters broadcast")
     x = trainer.stack_inputs(synth_batch(100 + rank, dev))   # resident in HBM before the timed region
 
     def barrier():
@@ -503,9 +559,43 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        trainer.step(x)
-    barrier()
+    # N > 1: which stream should the step's kernels run on?  The conv workgroups take whole CUs, so RCCL's reduction
+    # kernels (on RCCL's own stream, which torch gives no handle on) only get CUs as a launch drains.
+    # The knob is on the COMPUTE side: a stream whose CU mask leaves one CU per XCD free.  Time three steps each way in the
+    # warm-up, keep the faster (the max over ranks decides, so every rank picks the same), say which in `config`.
+    compute_stream, stream_choice = None, {}
+    if world > 1 and os.environ.get("ZNS_BENCH_CU_MASK", "auto") != "off":
+        try:
+            masked = cu_masked_stream(dev, reserve_per_xcd=1)
+        except Exception as e:                                # noqa: BLE001 -- an optional knob: report, do not fail the run
+            masked, stream_choice = None, {"compute_stream": "plain", "cu_mask_error": repr(e)[:200]}
+        if masked is not None:
+            def timed3(stream):
+                with torch.cuda.stream(stream):
+                    trainer.step(x)
+                    barrier()
+                    t0 = time.perf_counter()
+                    for _ in range(3):
+                        trainer.step(x)
+                    barrier()
+                    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                return float(t.item()) / 3 * 1e3
+            ms_plain = timed3(torch.cuda.current_stream())
+            ms_masked = timed3(masked)
+            use_masked = ms_masked < ms_plain or os.environ.get("ZNS_BENCH_CU_MASK") == "on"
+            compute_stream = masked if use_masked else None
+            stream_choice = {"compute_stream": "cu-masked (one CU per XCD left to RCCL)" if use_masked else "plain",
+                             "warmup_ms_per_step_plain_stream": ms_plain, "warmup_ms_per_step_cu_masked_stream": ms_masked}
+        phase(f"compute stream chosen: {stream_choice.get('compute_stream')}")
+    import contextlib
+    on_stream = (lambda: torch.cuda.stream(compute_stream)) if compute_stream is not None else contextlib.nullcontext
+
+    with on_stream():
+        for _ in range(args.warmup):
+            trainer.step(x)
+        barrier()
+    phase(f"warm-up ({args.warmup} steps)")
 
     # events around the dominant kernel, recorded by the library on the launch stream
     K = args.steps
@@ -519,15 +609,17 @@ def main():
     a1 = _lib.ptr_array([e.cuda_event for e in ev1])
     _lib.check(L.zns_probe_arm(PROBE["kind"], PROBE["cin"], PROBE["cout"], PROBE["kh"], a0, a1, K), "probe_arm")
 
-    barrier()
-    t0 = time.perf_counter()
-    out = None
-    for _ in range(K):
-        out = trainer.step(x)
-    barrier()
-    dt = time.perf_counter() - t0
+    with on_stream():
+        barrier()
+        t0 = time.perf_counter()
+        out = None
+        for _ in range(K):
+            out = trainer.step(x)
+        barrier()
+        dt = time.perf_counter() - t0
     nprobe = L.zns_probe_count()
     L.zns_probe_arm(0, 0, 0, 0, None, None, 0)
+    phase(f"timed region ({K} steps, {dt / K * 1e3:.2f} ms per step on this rank)")
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -539,18 +631,20 @@ def main():
         # exposed communication: the same K steps with the gradient all-reduce switched off (replicas drift apart, which
         # is irrelevant after the timed region); exposed = with - without.  Every rank runs it: same barriers.
         reducer, trainer.reducer = trainer.reducer, None
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(K):
-            trainer.step(x)
-        barrier()
-        dt_nc = time.perf_counter() - t1
+        with on_stream():
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(K):
+                trainer.step(x)
+            barrier()
+            dt_nc = time.perf_counter() - t1
         trainer.reducer = reducer
         tnc = torch.tensor([dt_nc], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tnc, op=torch.distributed.ReduceOp.MAX)
         dt_nc = float(tnc.item())
         comm = {"comm_exposed_ms": (dt - dt_nc) / K * 1e3, "ms_per_step_without_allreduce": dt_nc / K * 1e3,
-                "allreduce_bytes": trainer.n_flat * 4, "allreduce_buckets": len(trainer.buckets)}
+                "allreduce_bytes": trainer.n_flat * 4, "allreduce_buckets": len(trainer.buckets), **stream_choice}
+        phase("exposed-communication probe")
 
     if rank == 0:
         kms = [a.elapsed_time(b) for a, b in zip(ev0[:min(K, nprobe)], ev1[:min(K, nprobe)])]
@@ -590,22 +684,29 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": PROBE["traffic"],
                          "traffic_source": PROBE["traffic_source"], "kernel_ms": kavg, "launches_timed": len(kms)},
         }
-        if world == 1 and not args.no_extras:
-            del trainer, model
-            torch.cuda.empty_cache()
-            cpu = not args.no_cpu_baseline
-            res["config"].update(measure_module_path(dev))
-            res["config"]["module_path_vs_fused"] = res["config"]["module_path_ms_per_step"] / res["ms_per_step"]
-            res["config"]["xqt"] = measure_xqt(dev, cpu)
-            res["config"]["finetune"] = measure_finetune(dev, cpu)
-            res["config"].update(measure_pipeline(dev))
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline()
-            res["cpu_baseline"]["sample"] += ("; GPU-utilisation samplers see little on this command: the timed GPU region is "
-                                              "about a second inside tens of seconds of CPU baseline")
+        # everything below runs AFTER the timed region; if any of it raises, the headline line is still printed
+        try:
+            if world == 1 and not args.no_extras:
+                del trainer, model
+                torch.cuda.empty_cache()
+                cpu = not args.no_cpu_baseline
+                res["config"].update(measure_module_path(dev))
+                res["config"]["module_path_vs_fused"] = res["config"]["module_path_ms_per_step"] / res["ms_per_step"]
+                res["config"]["xqt"] = measure_xqt(dev, cpu)
+                res["config"]["finetune"] = measure_finetune(dev, cpu)
+                res["config"].update(measure_pipeline(dev))
+            if world == 1 and not args.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline()
+                res["cpu_baseline"]["sample"] += ("; GPU-utilisation samplers see little on this command: the timed GPU region is "
+                                                  "about a second inside tens of seconds of CPU baseline")
+        except Exception as e:                                # noqa: BLE001
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            res["config"]["extras_error"] = repr(e)[:300]
         print(json.dumps(res), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
+    phase("done")
 
 
 if __name__ == "__main__":

@@ -104,6 +104,22 @@ def test_bench_self_launches_its_ranks_without_torchrun():
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["steps"] == 2 and r["warmup"] == 1 and r["config"]["parallelism"] == "dp2"
     assert abs(r["value"] - 2 * 1000.0 / r["ms_per_step"]) < 1e-6 * r["value"]
+    # every rank reports its phases on stderr as it passes them (what a hung 8-GPU run would be read from) ...
+    for rk in (0, 1):
+        for ph in ("import ok", "init_process_group(gloo) ok", "trainer built, rank 0's parameters broadcast ok", "warm-up (1 steps) ok",
+                   "timed region (2 steps", "done ok"):
+            assert f"[rank {rk}] {ph}" in out.stderr, (rk, ph, out.stderr[-2000:])
+    # ... and the warm-up chose the compute stream (plain, or CU-masked so that RCCL's kernels find free CUs) by timing both
+    c = r["config"]
+    assert c["compute_stream"] in ("plain", "cu-masked (one CU per XCD left to RCCL)")
+    assert c.get("cu_mask_error") or (c["warmup_ms_per_step_plain_stream"] > 0 and c["warmup_ms_per_step_cu_masked_stream"] > 0)
+    # a rank that dies takes the job down quickly, and the launcher relays every rank's last lines
+    env_fail = dict(env, ZNS_BENCH_FAIL_RANK="1", ZNS_BENCH_PG_TIMEOUT="60")
+    dead = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                          capture_output=True, text=True, timeout=600, cwd=ROOT, env=env_fail)
+    assert dead.returncode != 0 and not [l for l in dead.stdout.splitlines() if l.startswith("{")]
+    assert "rank 1 exited with code 7" in dead.stderr and "---- rank 1: last" in dead.stderr and "---- rank 0: last" in dead.stderr
+    assert "ZNS_BENCH_FAIL_RANK: exiting with code 7" in dead.stderr.split("---- rank 1: last")[1]
     # and a launch that cannot work says so with a non-zero exit instead of hanging or printing a number
     env.pop("ZNS_BENCH_BACKEND")
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],

@@ -14,9 +14,10 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+def init_from_env(backend: Optional[str] = None, timeout_s: Optional[float] = None) -> Tuple[int, int, int]:
     """Initialise the default process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).
-    Returns (rank, world_size, local_rank).  A single process (no env) needs no group."""
+    Returns (rank, world_size, local_rank).  A single process (no env) needs no group.  timeout_s: rendezvous and
+    collective timeout (torch's default is 10-30 minutes: a rank that never shows up should fail the job sooner)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -27,7 +28,11 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {}
+        if timeout_s is not None:
+            import datetime
+            kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, local
 
 
