@@ -14,7 +14,7 @@ for n, clips in cases:
     g = torch.Generator().manual_seed(n + clips)
     y = (0.1 * torch.randn(clips, n, generator=g)).cuda()
     sep = generate_XQT_batch(y, 16000, "vqt", stages=3 | _lib.ZNS_XQT_SEPARATE)
-    fus = generate_XQT_batch(y, 16000, "vqt", stages=3 | _lib.ZNS_XQT_MARCH)
+    fus = generate_XQT_batch(y, 16000, "vqt", stages=3 | _lib.ZNS_XQT_FUSED)
     torch.cuda.synchronize()
     eq = torch.equal(sep, fus)
     d = (sep - fus).abs()
