@@ -16,7 +16,7 @@
 //   * waves 8..11, the filter bank on the fp32 matrix pipe: v_mfma_f32_16x16x4_f32 (bit for bit the fmaf chain over its
 //     four taps, tools/ubench_mfma16_order.hip, so the results equal xqt_filter_kernel's), 16 frames x 16 rows per
 //     instruction, the 24 real rows of an octave = two row tiles.  Wave w owns octave w (128 taps) plus a share of the short
-//     octaves; its A operands stay in registers for the whole kernel.  A tile of octave i = frames 16 u - FO_i .. + 15 of
+//     octaves (2688 / 2560 / 2560 / 2688 matrix-pipe cycles per step); its A operands stay in registers for the whole kernel.  A tile of octave i = frames 16 u - FO_i .. + 15 of
 //     step u (FO_i: the few frames octave i runs behind so that its last window is complete), staged by the wave itself
 //     from window i into a private image with two pad words per hop (frame stride = 2 x odd: conflict-free B reads),
 //     element-wise with librosa's reflect padding for the tiles that touch a signal end.  No workgroup barrier inside a step.
@@ -80,7 +80,7 @@ __host__ __device__ constexpr int SS_(int i) { return i < 2 ? 130 : i == 7 ? 2 :
 __host__ __device__ constexpr int NEL_(int i) { return i == 0 ? 16 * 128 : 15 * HOP_(i) + NFFT_(i); }
 __host__ __device__ constexpr int STG_(int i) { return i < 2 ? 16 * 130 : ((16 * SS_(i) + NFFT_(i) + 8 + 7) / 8) * 8; }
 // wave w's staging region: [octave w][its short octaves]
-constexpr int STG_W0 = STG_(0) + STG_(7) + STG_(4), STG_W1 = STG_(1) + STG_(6), STG_W2 = STG_(2) + STG_(5), STG_W3 = STG_(3) + STG_(4);
+constexpr int STG_W0 = STG_(0) + STG_(7) + STG_(4), STG_W1 = STG_(1) + STG_(6), STG_W2 = STG_(2) + STG_(5), STG_W3 = STG_(3) + STG_(4) + STG_(7);
 constexpr int STG_FLOATS = STG_W0 + STG_W1 + STG_W2 + STG_W3;
 constexpr int LDS_FLOATS = WIN_FLOATS + STG_FLOATS;
 
@@ -497,45 +497,51 @@ template <int WV>
 __device__ __forceinline__ void filter_role(const Args& P, float* __restrict__ lds, int b, int nmine, int steps) {
     const int lane = threadIdx.x & 63;
     float* __restrict__ stg = lds + WIN_FLOATS + (WV == 0 ? 0 : WV == 1 ? STG_W0 : WV == 2 ? STG_W0 + STG_W1 : STG_W0 + STG_W1 + STG_W2);
-    // the octaves of this wave: WV (128 taps, both row tiles) and S1 (, 4): wave 0 octave 7 and row tile 1 of octave 4,
-    // wave 1 octave 6, wave 2 octave 5, wave 3 row tile 0 of octave 4 -- 2816 / 2560 / 2560 / 2560 matrix-pipe cycles per step
+    // The octaves of this wave: WV (128 taps, both row tiles), S1 and -- waves 0 and 3 -- one row tile of E:
+    //   wave 0: octave 0 + row tile 0 of octave 7 + row tile 1 of octave 4      2048 + 128 + 512 = 2688 matrix-pipe cycles per step
+    //   wave 1: octave 1 + octave 6                                              2048 + 512       = 2560
+    //   wave 2: octave 2 + octave 5                                              2048 + 512       = 2560
+    //   wave 3: octave 3 + row tile 0 of octave 4 + row tile 1 of octave 7      2048 + 512 + 128 = 2688
+    // (both waves that share an octave stage it for themselves: 46 or 304 floats, cheaper than a barrier)
     constexpr int S1 = WV == 0 ? 7 : WV == 1 ? 6 : WV == 2 ? 5 : 4;
-    constexpr int S1_RTM = WV == 3 ? 1 : 3;
-    float* __restrict__ stgB = stg, * __restrict__ stgS = stg + STG_(WV), * __restrict__ stgE = stg + STG_(0) + STG_(7);
+    constexpr int S1_RTM = (WV == 0 || WV == 3) ? 1 : 3;
+    constexpr bool HAS_E = WV == 0 || WV == 3;
+    constexpr int EO = WV == 0 ? 4 : 7;
+    float* __restrict__ stgB = stg, * __restrict__ stgS = stg + STG_(WV), * __restrict__ stgE = stg + STG_(WV) + STG_(S1);
     float a0[32], a1[32];
     load_operand<32>(P.fira16 + P.offa16[WV], lane, a0);
     load_operand<32>(P.fira16 + P.offa16[WV] + 32 * 64, lane, a1);
     float c0[NFFT_(S1) / 4], c1[NFFT_(S1) / 4];
     load_operand<NFFT_(S1) / 4>(P.fira16 + P.offa16[S1], lane, c0);
-    load_operand<NFFT_(S1) / 4>(P.fira16 + P.offa16[S1] + (NFFT_(S1) / 4) * 64, lane, c1);
-    float e1[16];
-    if constexpr (WV == 0) load_operand<16>(P.fira16 + P.offa16[4] + 16 * 64, lane, e1);
-    Oct<WV> OB; Oct<S1> OS; Oct<4> OE;
+    if constexpr (S1_RTM & 2) load_operand<NFFT_(S1) / 4>(P.fira16 + P.offa16[S1] + (NFFT_(S1) / 4) * 64, lane, c1);
+    float e1[NFFT_(EO) / 4];
+    if constexpr (HAS_E) load_operand<NFFT_(EO) / 4>(P.fira16 + P.offa16[EO] + (NFFT_(EO) / 4) * 64, lane, e1);
+    Oct<WV> OB; Oct<S1> OS; Oct<EO> OE;
     OB.init(P, lane, b); OS.init(P, lane, b); OE.init(P, lane, b);
-    // the one filter wave of a SIMD is its youngest wave and loses issue arbitration to the two pyramid waves, but the step
-    // lasts as long as ITS chain (stage -> 80 dependent-paced MFMAs -> epilogue): give it the issue slots it asks for
+    // the one filter wave of a SIMD is its youngest wave and loses issue arbitration to the two pyramid waves: give it the
+    // issue slots it asks for (3.25 -> 2.90 ms per 4096 clips)
     if (!(P.dbg & 64)) __builtin_amdgcn_s_setprio(3);
     for (int s = 0; s < steps; ++s) {
         const int par = s & 1;
         SQ_STAMP(P, s, 0);
         OB.begin(P, nmine); OS.begin(P, nmine);
-        if constexpr (WV == 0) OE.begin(P, nmine);
+        if constexpr (HAS_E) OE.begin(P, nmine);
         const bool stage = !(P.dbg & 4);
         // all of the step's interior tiles: window -> registers together (one LDS latency), then registers -> images
-        float4 vb[Oct<WV>::NIT], vs[Oct<S1>::NIT], ve[Oct<4>::NIT];
+        float4 vb[Oct<WV>::NIT], vs[Oct<S1>::NIT], ve[Oct<EO>::NIT];
         if (stage && OB.tile && !OB.edge) OB.stage_load(lds, par, lane, vb);
         if (stage && OS.tile && !OS.edge) OS.stage_load(lds, par, lane, vs);
-        if constexpr (WV == 0) { if (stage && OE.tile && !OE.edge) OE.stage_load(lds, par, lane, ve); }
+        if constexpr (HAS_E) { if (stage && OE.tile && !OE.edge) OE.stage_load(lds, par, lane, ve); }
         if (stage && OB.tile) { if (OB.edge) stage_edge<WV>(P.wav + (long long)OB.clip * P.n, P.len[WV], OB.worig(P), OB.Ff, lds, stgB, par, lane); else OB.stage_store(stgB, lane, vb); }
         if (stage && OS.tile) { if (OS.edge) stage_edge<S1>(P.wav + (long long)OS.clip * P.n, P.len[S1], OS.worig(P), OS.Ff, lds, stgS, par, lane); else OS.stage_store(stgS, lane, vs); }
-        if constexpr (WV == 0) { if (stage && OE.tile) { if (OE.edge) stage_edge<4>(P.wav + (long long)OE.clip * P.n, P.len[4], OE.worig(P), OE.Ff, lds, stgE, par, lane); else OE.stage_store(stgE, lane, ve); } }
+        if constexpr (HAS_E) { if (stage && OE.tile) { if (OE.edge) stage_edge<EO>(P.wav + (long long)OE.clip * P.n, P.len[EO], OE.worig(P), OE.Ff, lds, stgE, par, lane); else OE.stage_store(stgE, lane, ve); } }
         SQ_STAMP(P, s, 1);
         if (OB.tile) octave_mma<WV, 3>(P, OB, stgB, lane, a0, a1);
         SQ_STAMP(P, s, 2);
         if (OS.tile) octave_mma<S1, S1_RTM>(P, OS, stgS, lane, c0, c1);
-        if constexpr (WV == 0) { if (OE.tile) octave_mma<4, 2>(P, OE, stgE, lane, e1, e1); }
+        if constexpr (HAS_E) { if (OE.tile) octave_mma<EO, 2>(P, OE, stgE, lane, e1, e1); }
         OB.advance(P, b); OS.advance(P, b);
-        if constexpr (WV == 0) OE.advance(P, b);
+        if constexpr (HAS_E) OE.advance(P, b);
         SQ_STAMP(P, s, 3);
         __syncthreads();
         SQ_STAMP(P, s, 4);
