@@ -453,6 +453,26 @@ def test_fused_kernel_equals_the_per_stage_launches_bitwise(n, clips):
 
 
 @pytest.mark.gpu
+def test_fused_kernel_equals_the_per_stage_launches_on_random_shapes():
+    """Twenty-four drawn (length, batch) pairs -- lengths with every residue mod 16, batches that make the launcher cut clips
+    into 1 .. 20 chunks or stream several clips per workgroup: bitwise equality again (the shapes of the test above are
+    the ones thought of; these are the ones not thought of)."""
+    from zeronotesamba_amd import _lib
+    from zeronotesamba_amd.processing.input_rep import generate_XQT_batch
+    rng = np.random.default_rng(20240)
+    for trial in range(24):
+        n = int(rng.integers(1100, 90000)) if trial % 3 else int(rng.integers(1100, 9000))
+        clips = int(rng.integers(1, 48)) if trial % 4 else int(rng.integers(250, 700))
+        if clips * n > 40_000_000:
+            clips = max(1, 40_000_000 // n)
+        g = torch.Generator().manual_seed(1000 + trial)
+        y = (0.1 * torch.randn(clips, n, generator=g)).cuda()
+        sep = generate_XQT_batch(y, 16000, "vqt", stages=3 | _lib.ZNS_XQT_SEPARATE)
+        fus = generate_XQT_batch(y, 16000, "vqt", stages=3 | _lib.ZNS_XQT_FUSED)
+        assert torch.equal(sep, fus), (trial, n, clips, (sep - fus).abs().max().item())
+
+
+@pytest.mark.gpu
 def test_fused_kernel_repeats_and_needs_no_workspace():
     """The persistent kernel keeps its state in LDS: running it twice must give the same bits, it must not touch the
     workspace (a NaN-filled one stays NaN-filled), and a non-finite sample must stay inside its own clip and its own

@@ -46,7 +46,7 @@ def cpu_oracle(n_clips=2):
 
 
 if __name__ == "__main__":
-    if "--stages" in sys.argv:       # e.g. 19 = 3 | ZNS_XQT_EXACT, 11 = 3 | ZNS_XQT_MARCH
+    if "--stages" in sys.argv:       # e.g. 7 = 3 | ZNS_XQT_SEPARATE, 11 = 3 | ZNS_XQT_FUSED, 19 = 3 | ZNS_XQT_EXACT
         STAGES = int(sys.argv[sys.argv.index("--stages") + 1])
     sizes = ((32, 50), (64, 30), (128, 20), (256, 10), (512, 10), (4096, 3))
     if "--only" not in sys.argv: sizes = (sizes[0], sizes[4], sizes[5])
