@@ -8,9 +8,9 @@ for p in plans:
     env = dict(os.environ)
     if p != "default":
         env["ZNS_XQT_PLAN"] = p
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_xqt.py"), "--only", n], env=env, capture_output=True, text=True)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_xqt.py"), "--only", n, "--stages", "7"], env=env, capture_output=True, text=True)
     try:
         r = json.loads(out.stdout.strip().splitlines()[0])
-        print(p, round(r["ms"] * 1e3, 1), "us")
+        print(p, "whole", round(r["ms"] * 1e3, 1), "us  pyramid", round(r["pyramid_ms"] * 1e3, 1), "us  filter", round(r["filter_ms"] * 1e3, 1), "us")
     except Exception:
         print(p, "failed", out.stderr[-200:])

@@ -49,6 +49,84 @@ __device__ __forceinline__ float xqt_log_magnitude(float re, float im) {
     return __logf(__builtin_amdgcn_sqrtf(re * re + im * im) + 1e-9f);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The default pyramid's 63-tap chain, packed.  Order per output, as resampy: left wing i = 0..31 (x[2t - i]), right wing
+// r = 0..30 (x[2t + 1 + r], weight l[r + 1]), one fused multiply-add per tap.  A non-packed v_fma_f32 issues at 4.2 cycles
+// per wave and SIMD like every vector instruction (tools/ubench_valu.hip: 75 TFLOP/s; the 157 TFLOP/s vector peak is
+// v_pk_fma_f32), so the taps are PACKED without changing any output's own order: outputs k (even) and k + 1 share a
+// register pair, and tap i of output k reads the same sample as tap i + 2 of output k + 1 (x[2k - i] = x[2(k + 1) - (i + 2)]):
+// one v_pk_fma_f32 with the tap pair (l[i], l[i + 2]) from scalar registers and that sample broadcast to both halves
+// (op_sel).  Output k + 1 simply runs two taps ahead in the left wing and two behind in the right one; the four taps at
+// each wing's ends that have no partner are single v_fma_f32.  67 instructions per output pair instead of 126, every
+// rounding where it was (the results equal the plain v_fma_f32 chain bit for bit).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct TapPairs {
+    f32x2 p[30];                 // p[i] = (l[i], l[i + 2])
+};
+// acc.lo += t.lo * x[H], acc.hi += t.hi * x[H]
+template <int H>
+__device__ __forceinline__ void pk_left(f32x2& acc, const f32x2 t, const f32x2 x) {
+    if (H == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(t), "v"(x));
+    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(t), "v"(x));
+}
+// acc.lo += t.hi * x[H], acc.hi += t.lo * x[H]
+template <int H>
+__device__ __forceinline__ void pk_right(f32x2& acc, const f32x2 t, const f32x2 x) {
+    if (H == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1]" : "+v"(acc) : "s"(t), "v"(x));
+    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(t), "v"(x));
+}
+// 2 NP consecutive outputs from the thread's span of 64 + 4 NP samples: xp[q] = samples (2 q, 2 q + 1), sample n belongs to
+// input index 2 t0 - 32 + n of the first output t0.
+template <int NP>
+__device__ __forceinline__ void taps63_pairs(const f32x2 (&xp)[32 + 2 * NP], const TapPairs& w, float (&out)[2 * NP]) {
+    auto X = [&](int n) -> float { return xp[n >> 1][n & 1]; };
+    const float l0 = w.p[0].x, l1 = w.p[1].x, l2 = w.p[0].y, l30 = w.p[28].y, l31 = w.p[29].y;
+    f32x2 acc[NP];
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+        // left wing of the odd output (k + 1 = 2 m + 1): its taps 0 and 1 have no partner
+        float hi = __builtin_fmaf(l0, X(34 + 4 * m), 0.f);
+        hi = __builtin_fmaf(l1, X(33 + 4 * m), hi);
+        acc[m] = f32x2{0.f, hi};
+    }
+#pragma unroll
+    for (int i = 0; i < 30; ++i)
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+            const int n = 32 + 4 * m - i;                              // x[2k - i], k = 2 m
+            if (n & 1) pk_left<1>(acc[m], w.p[i], xp[n >> 1]); else pk_left<0>(acc[m], w.p[i], xp[n >> 1]);
+        }
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+        // the even output finishes its left wing (taps 30, 31) and opens its right wing (r = 0, 1) alone
+        float lo = acc[m].x;
+        lo = __builtin_fmaf(l30, X(2 + 4 * m), lo);
+        lo = __builtin_fmaf(l31, X(1 + 4 * m), lo);
+        lo = __builtin_fmaf(l1, X(33 + 4 * m), lo);
+        lo = __builtin_fmaf(l2, X(34 + 4 * m), lo);
+        acc[m].x = lo;
+    }
+#pragma unroll
+    for (int r = 2; r < NR; ++r)
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+            const int n = 33 + 4 * m + r;                              // x[2k + 1 + r]: tap r of output k, tap r - 2 of output k + 1
+            if (n & 1) pk_right<1>(acc[m], w.p[r - 1], xp[n >> 1]); else pk_right<0>(acc[m], w.p[r - 1], xp[n >> 1]);
+        }
+#pragma unroll
+    for (int m = 0; m < NP; ++m) {
+        // the odd output's last two taps (r = 29, 30)
+        float hi = acc[m].y;
+        hi = __builtin_fmaf(l30, X(64 + 4 * m), hi);
+        hi = __builtin_fmaf(l31, X(65 + 4 * m), hi);
+        out[2 * m] = acc[m].x;
+        out[2 * m + 1] = hi;
+    }
+    // unpinned, the optimiser sinks each output's chain into the branch that later keeps or zeroes it (serial chains)
+#pragma unroll
+    for (int k = 0; k < 2 * NP; ++k) asm volatile("" : "+v"(out[k]));
+}
+
 // The fused kernel (zns_xqt_stream.hip): both stages in ONE launch, pyramid levels never leave LDS.  vqt bank only.
 bool xqt_stream_supported(const Bank* b, int n_clips, int n_samples);
 unsigned long long* xqt_stream_stamps();   // tuning aid, see ZNS_XQT_STAMPS

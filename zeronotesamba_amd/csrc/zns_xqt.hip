@@ -4,7 +4,8 @@
 // decimation).  Here the per-octave "rfft -> sparse basis product" is folded on the host (float64) into an
 // equivalent strided complex FIR bank g[k][n] (<= 12 x 256 taps per octave).  Two stages:
 //   * the octave pyramid (seven 2:1 decimations).  Default arithmetic: resampy's taps (rounded once to float32) in
-//     resampy's order, one float32 fused multiply-add per tap -- HBM-bound as SURVEY 8(d) prices the stage.  resampy itself
+//     resampy's order, one float32 fused multiply-add per tap (issued in pairs as v_pk_fma_f32, zns_xqt.h) -- HBM-bound as
+//     SURVEY 8(d) prices the stage.  resampy itself
 //     rounds a float64 product-sum to float32 after every tap; the two differ in a fraction of those roundings by one unit in
 //     the last place, which is the size of the restatement's own rounding noise (tests/test_vqt.py states the distance).
 //     ZNS_XQT_EXACT selects the validation implementation that emulates resampy's rounding bit for bit: three dependent
@@ -369,31 +370,21 @@ __global__ void __launch_bounds__(256) decimate_chain_kernel(DecChain P, const D
 constexpr int DCF_PLANE = 4 * DC_S + 44;      // floats per plane: 265 columns of one chunk, padded to 16 (mod 64) banks
 constexpr int DCF_WIN = 2 * DCF_PLANE;
 
-__device__ __forceinline__ void dcf_taps63(const float* __restrict__ win, int g, const DecTapsF& w, float (&acc)[4]) {
+__device__ __forceinline__ void dcf_taps63(const float* __restrict__ win, int g, const TapPairs& w, float (&acc)[4]) {
     const float4* __restrict__ pa = reinterpret_cast<const float4*>(win) + g;
     const float4* __restrict__ pb = reinterpret_cast<const float4*>(win + DCF_PLANE) + g;
-    float xs[72];
+    f32x2 xp[36];                // xp[q] = samples (2 q, 2 q + 1) of the window span 8 g .. 8 g + 71
 #pragma unroll
     for (int h = 0; h < 9; ++h) {
         float4 a = pa[h], b = pb[h];
         if (h == 0) asm volatile("" : "+v"(a.x));     // sample 0 is never used: keeps the compiler from splitting the 16-byte reads
-        xs[8 * h] = a.x; xs[8 * h + 1] = a.y; xs[8 * h + 2] = a.z; xs[8 * h + 3] = a.w;
-        xs[8 * h + 4] = b.x; xs[8 * h + 5] = b.y; xs[8 * h + 6] = b.z; xs[8 * h + 7] = b.w;
+        xp[4 * h] = f32x2{a.x, a.y}; xp[4 * h + 1] = f32x2{a.z, a.w};
+        xp[4 * h + 2] = f32x2{b.x, b.y}; xp[4 * h + 3] = f32x2{b.z, b.w};
     }
-#pragma unroll
-    for (int i = 0; i < NL; ++i)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] = __builtin_fmaf(w.l[i], xs[32 + 2 * k - i], acc[k]);
-#pragma unroll
-    for (int r = 0; r < NR; ++r)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[k] = __builtin_fmaf(w.l[r + 1], xs[33 + 2 * k + r], acc[k]);
-    // the callers keep or zero each sum by its output index: unpinned, the optimiser sinks each output's chain into its own
-    // conditional block: four serial chains one after the other, no instruction-level parallelism, split loads
-    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+    taps63_pairs<2>(xp, w, acc);                      // the packed chain (zns_xqt.h): same taps, same order, same bits
 }
 
-__global__ void __launch_bounds__(256) decimate_chain_f32_kernel(DecChain P, DecTapsF W) {
+__global__ void __launch_bounds__(256) decimate_chain_f32_kernel(DecChain P, TapPairs W) {
     extern __shared__ __attribute__((aligned(16))) float fwin[];      // [2][DCF_WIN] (one buffer when nlev == 1)
     const int clip = blockIdx.x / P.blocks_per_clip, b = blockIdx.x - clip * P.blocks_per_clip;
     auto T0 = [&](int j) { return 32 + (b * 4 * P.GL - 32) * (1 << (P.nlev - 1 - j)); };
@@ -423,7 +414,7 @@ __global__ void __launch_bounds__(256) decimate_chain_f32_kernel(DecChain P, Dec
         float* __restrict__ y = P.dst[j] + (long long)clip * P.dst_stride[j];
         const int T0j = T0(j);
         for (int g = threadIdx.x; g < P.G[j]; g += 256) {
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            float acc[4];
             dcf_taps63(src, g, W, acc);
             const int t0 = T0j + 4 * g;
             float v[4];
@@ -787,16 +778,22 @@ int zns_xqt_stages_f32(const float* wav, int n_clips, int n_samples, int sample_
     if (stages == 3 && !(plan_flags & ZNS_XQT_SEPARATE)) {
         const bool can = !exact && xqt_stream_supported(b, n_clips, n_samples);
         ZNS_CHECK_ARG(can || !(plan_flags & ZNS_XQT_FUSED), "xqt: the fused kernel is built for the vqt bank and the default pyramid arithmetic");
-        // a handful of clips cannot fill the fused kernel's pipeline (its nine steps of ramp weigh as much as the work:
-        // 36 us against 28 us for one clip, equal at 32, 2.80 against 3.40 ms at 4096; tools/bench_xqt_sizes.py)
-        if (can && ((plan_flags & ZNS_XQT_FUSED) || n_clips >= 16)) return xqt_stream_launch(b, wav, n_clips, n_samples, out, st);
+        // small batches cannot fill the fused kernel's pipeline (two warm-up steps and nine steps of systolic lag around an
+        // item's five): one 10 s clip 37 us against 22 us for the three chained pyramid launches + the filter bank, 32 clips
+        // 53 against 45, 128 clips 114 against 106, 256 clips 195 against 218, 4096 clips 2.73 against 3.26 ms
+        // (tools/bench_xqt_sizes.py, profiles/r04_xqt_bench_sizes.json)
+        if (can && ((plan_flags & ZNS_XQT_FUSED) || n_clips >= 192)) return xqt_stream_launch(b, wav, n_clips, n_samples, out, st);
     }
     // decimation pyramid: levels 1..7, grouped into chains (one launch each).  Default plan: the two big levels on
     // their own (no recomputed halo where 3/4 of the taps are), then chains of two and three (the small levels' launches
     // are latency-bound: 6.5 us each for a 32-clip batch).  ZNS_XQT_PLAN="n1,n2,.." overrides the grouping (tuning aid).
     if (stages & 1) {
-        // big batches: one launch per level (the fused tail recomputes halos and runs few blocks); small ones: fused tail
-        int plan[XQ_OCT] = {1, 1, 2, 3, 1, 1, 1}, nplan = 4;     // tools/exp_xqt_plan_sweep.py: 87 us against 91 for {1,1,1,4} at 32 clips
+        // big batches: one launch per level (the fused tail recomputes halos and runs few blocks); small ones: chains of
+        // 2 + 2 + 3 levels.  tools/exp_xqt_plan_sweep.py, 32 clips, whole transform with the float32 pyramid: 49.6 us against
+        // 51.8 for {1,1,2,3} (the exact pyramid's best: its taps cost six times as much, halos weigh more), 50.8 for {3,4},
+        // 59.5 for one launch per level -- at this size a launch is mostly latency and there are three instead of four
+        int plan[XQ_OCT] = {2, 2, 3, 1, 1, 1, 1}, nplan = 3;
+        if (exact) { plan[0] = 1; plan[1] = 1; plan[2] = 2; plan[3] = 3; nplan = 4; }
         if (n_clips >= 256) { nplan = 7; for (int i = 0; i < 7; ++i) plan[i] = 1; }
         if (const char* e = getenv("ZNS_XQT_PLAN")) {
             nplan = 0;
@@ -840,8 +837,8 @@ int zns_xqt_stages_f32(const float* wav, int n_clips, int n_samples, int sample_
                 }
                 hipLaunchKernelGGL(decimate_chain_kernel, grid, dim3(256), lds, st, P, b->taps);
             } else {
-                DecTapsF W;
-                for (int i = 0; i < NL; ++i) W.l[i] = b->tapsf[i];
+                TapPairs W;
+                for (int i = 0; i < 30; ++i) W.p[i] = f32x2{b->tapsf[i], b->tapsf[i + 2]};
                 const size_t lds = (size_t)(nlev > 1 ? 2 : 1) * DCF_WIN * sizeof(float);
                 hipLaunchKernelGGL(decimate_chain_f32_kernel, grid, dim3(256), lds, st, P, W);
             }

@@ -101,32 +101,8 @@ static_assert(LDS_FLOATS * 4 <= 160 * 1024, "LDS");
 
 __device__ __forceinline__ int waddr(int woff, int pl, int buf, int c) { return woff + (4 * buf + (c & 3)) * pl + (c >> 2) * 4; }
 
-// 63 taps x 8 outputs from 20 chunks of a window: p0 = plane 0 at the thread's first column, pl = floats per plane.
-// Order per output, as resampy: left wing i = 0..31 (x[2t - i]), right wing r = 0..30 (x[2t + 1 + r], weight l[r + 1]), one
-// fused multiply-add per tap.  A non-packed v_fma_f32 issues at 4.2 cycles per wave and SIMD like every vector
-// instruction (tools/ubench_valu.hip: 75 TFLOP/s; the 157 TFLOP/s vector peak is v_pk_fma_f32), so the taps are PACKED
-// without changing any output's own order: outputs k (even) and k + 1 share a register pair, and tap i of output k reads
-// the same sample as tap i + 2 of output k + 1 (x[2k - i] = x[2(k + 1) - (i + 2)]): one v_pk_fma_f32 with the tap pair
-// (l[i], l[i + 2]) from scalar registers and that sample broadcast to both halves (op_sel).  Output k + 1 simply runs two
-// taps ahead in the left wing and two behind in the right one; the four taps at each wing's ends that have no partner are
-// single v_fma_f32.  67 instructions per output pair instead of 126, every rounding where it was.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-struct TapPairs {
-    f32x2 p[30];                 // p[i] = (l[i], l[i + 2])
-};
-// acc.lo += t.lo * x[H], acc.hi += t.hi * x[H]
-template <int H>
-__device__ __forceinline__ void pk_left(f32x2& acc, const f32x2 t, const f32x2 x) {
-    if (H == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(t), "v"(x));
-    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(t), "v"(x));
-}
-// acc.lo += t.hi * x[H], acc.hi += t.lo * x[H]
-template <int H>
-__device__ __forceinline__ void pk_right(f32x2& acc, const f32x2 t, const f32x2 x) {
-    if (H == 0) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,0,1]" : "+v"(acc) : "s"(t), "v"(x));
-    else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(t), "v"(x));
-}
-
+// 63 taps x 8 outputs from 20 chunks of a window: p0 = plane 0 at the thread's first column, pl = floats per plane (the
+// packed tap chain itself: taps63_pairs, zns_xqt.h).
 __device__ __forceinline__ void taps63x8(const float* __restrict__ p0, int pl, const TapPairs& w, float (&out)[8]) {
     const float* __restrict__ p1 = p0 + pl;
     const float* __restrict__ p2 = p1 + pl;
@@ -147,51 +123,7 @@ __device__ __forceinline__ void taps63x8(const float* __restrict__ p0, int pl, c
         xp[8 * h + 4] = f32x2{c.x, c.y}; xp[8 * h + 5] = f32x2{c.z, c.w};
         xp[8 * h + 6] = f32x2{d.x, d.y}; xp[8 * h + 7] = f32x2{d.z, d.w};
     }
-    auto X = [&](int n) -> float { return xp[n >> 1][n & 1]; };
-    const float l0 = w.p[0].x, l1 = w.p[1].x, l2 = w.p[0].y, l30 = w.p[28].y, l31 = w.p[29].y;
-    f32x2 acc[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        // left wing of the odd output (k + 1 = 2 m + 1): its taps 0 and 1 have no partner
-        float hi = __builtin_fmaf(l0, X(34 + 4 * m), 0.f);
-        hi = __builtin_fmaf(l1, X(33 + 4 * m), hi);
-        acc[m] = f32x2{0.f, hi};
-    }
-#pragma unroll
-    for (int i = 0; i < 30; ++i)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int n = 32 + 4 * m - i;                              // x[2k - i], k = 2 m
-            if (n & 1) pk_left<1>(acc[m], w.p[i], xp[n >> 1]); else pk_left<0>(acc[m], w.p[i], xp[n >> 1]);
-        }
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        // the even output finishes its left wing (taps 30, 31) and opens its right wing (r = 0, 1) alone
-        float lo = acc[m].x;
-        lo = __builtin_fmaf(l30, X(2 + 4 * m), lo);
-        lo = __builtin_fmaf(l31, X(1 + 4 * m), lo);
-        lo = __builtin_fmaf(l1, X(33 + 4 * m), lo);
-        lo = __builtin_fmaf(l2, X(34 + 4 * m), lo);
-        acc[m].x = lo;
-    }
-#pragma unroll
-    for (int r = 2; r < NR; ++r)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int n = 33 + 4 * m + r;                              // x[2k + 1 + r]: tap r of output k, tap r - 2 of output k + 1
-            if (n & 1) pk_right<1>(acc[m], w.p[r - 1], xp[n >> 1]); else pk_right<0>(acc[m], w.p[r - 1], xp[n >> 1]);
-        }
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        // the odd output's last two taps (r = 29, 30)
-        float hi = acc[m].y;
-        hi = __builtin_fmaf(l30, X(64 + 4 * m), hi);
-        hi = __builtin_fmaf(l31, X(65 + 4 * m), hi);
-        out[2 * m] = acc[m].x;
-        out[2 * m + 1] = hi;
-    }
-    // unpinned, the optimiser sinks each output's chain into the branch that later keeps or zeroes it (serial chains)
-    asm volatile("" : "+v"(out[0]), "+v"(out[1]), "+v"(out[2]), "+v"(out[3]), "+v"(out[4]), "+v"(out[5]), "+v"(out[6]), "+v"(out[7]));
+    taps63_pairs<4>(xp, w, out);
 }
 
 struct Args {
@@ -585,7 +517,7 @@ int xqt_stream_launch(const Bank* b, const float* wav, int n_clips, int n_sample
     A.out = out;
     A.fira16 = b->fira16;
     for (int i = 0; i < XQ_OCT; ++i) A.offa16[i] = b->offa16[i];
-    for (int i = 0; i < 30; ++i) A.taps.p[i] = sq::f32x2{b->tapsf[i], b->tapsf[i + 2]};
+    for (int i = 0; i < 30; ++i) A.taps.p[i] = f32x2{b->tapsf[i], b->tapsf[i + 2]};
     A.n = n_samples;
     A.T = zns_xqt_frames(n_samples);
     A.vec0 = (n_samples % 4 == 0) && ((uintptr_t)wav % 16 == 0);
