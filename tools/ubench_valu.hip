@@ -35,7 +35,7 @@ int main() {
     hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 20000;
     for (int pk = 0; pk < 2; ++pk)
-        for (int wps = 1; wps <= 8; wps *= 2) {
+        for (int wps = 1; wps <= 4; wps *= 2) {
             const int threads = 64 * 4 * wps;
             auto launch = [&]() {
                 if (pk) hipLaunchKernelGGL(k<1>, dim3(256), dim3(threads), 0, 0, d, iters, 1.0001f);
