@@ -43,10 +43,19 @@ __device__ __forceinline__ float dc_div_sqrt_half(double x_float32_valued) {
 }
 
 // Epilogue of both filter-bank kernels: log(|V| + 1e-9) (input_rep.py:51-52, eps = 10e-10) with the hardware sqrt / log2
-// (1 ulp each: <= 2e-6 absolute in the log domain, a fiftieth of the parity tolerance, a fifth of the instructions of the
-// correctly rounded library forms)
+// (1 ulp each: <= 2e-6 absolute in the log domain, a fiftieth of the parity tolerance).  ln(m) = log2(m) * ln 2 is formed
+// exactly as the compiler's own expansion of logf forms it -- the product in extended precision, c + cc = ln 2 to 48 bits --
+// minus the part of that expansion that rescales denormal arguments: the argument here is never below 1e-9.  The epilogue
+// is most of the filter-bank waves' vector instructions in the fused kernel (ten of these per wave and step): 11
+// instructions instead of 22.
 __device__ __forceinline__ float xqt_log_magnitude(float re, float im) {
-    return __logf(__builtin_amdgcn_sqrtf(re * re + im * im) + 1e-9f);
+    const float m = __builtin_amdgcn_sqrtf(re * re + im * im) + 1e-9f;
+    const float y = __builtin_amdgcn_logf(m);                       // v_log_f32: log2
+    constexpr float c = 0x1.62e42ep-1f, cc = 0x1.efa39ep-25f;       // ln 2 = c + cc
+    const float r = y * c;
+    const float lo = __builtin_fmaf(y, cc, __builtin_fmaf(y, c, -r));
+    const float ln = __builtin_fmaf(c, y, lo);
+    return __builtin_fabsf(y) < __builtin_inff() ? ln : y;          // log(inf) = inf, log(NaN) = NaN
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -76,55 +85,83 @@ __device__ __forceinline__ void pk_right(f32x2& acc, const f32x2 t, const f32x2 
     else asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1]" : "+v"(acc) : "s"(t), "v"(x));
 }
 // 2 NP consecutive outputs from the thread's span of 64 + 4 NP samples: xp[q] = samples (2 q, 2 q + 1), sample n belongs to
-// input index 2 t0 - 32 + n of the first output t0.
+// input index 2 t0 - 32 + n of the first output t0.  The chain comes in phases so that a caller can request its samples in
+// the order of first use and start on the first while the last are still in flight:
+//   open        the odd outputs' taps 0, 1                                        samples 33 .. 46
+//   left<I0,I1> packed left-wing taps i = I0 .. I1 - 1                             samples 32 - (I1 - 1) .. 44 - I0   (+ 4 per pair)
+//   turn        the even outputs' taps 30, 31 and their right-wing taps 0, 1       samples 1 .. 14 and 33 .. 46
+//   right<R0,R1> packed right-wing taps r = R0 .. R1 - 1 (2 <= R0)                 samples 33 + R0 .. 45 + (R1 - 1)
+//   close       the odd outputs' taps r = 29, 30; results out                      samples 64 .. 77
+template <int NP>
+struct Taps63 {
+    f32x2 acc[NP];
+    template <class XP>
+    __device__ __forceinline__ void open(const XP& xp, const TapPairs& w) {
+        const float l0 = w.p[0].x, l1 = w.p[1].x;
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+            float hi = __builtin_fmaf(l0, xp[(34 + 4 * m) >> 1][0], 0.f);
+            hi = __builtin_fmaf(l1, xp[(33 + 4 * m) >> 1][1], hi);
+            acc[m] = f32x2{0.f, hi};
+        }
+    }
+    template <int I0, int I1, class XP>
+    __device__ __forceinline__ void left(const XP& xp, const TapPairs& w) {
+#pragma unroll
+        for (int i = I0; i < I1; ++i)
+#pragma unroll
+            for (int m = 0; m < NP; ++m) {
+                const int n = 32 + 4 * m - i;                              // x[2k - i], k = 2 m
+                if (n & 1) pk_left<1>(acc[m], w.p[i], xp[n >> 1]); else pk_left<0>(acc[m], w.p[i], xp[n >> 1]);
+            }
+    }
+    template <class XP>
+    __device__ __forceinline__ void turn(const XP& xp, const TapPairs& w) {
+        const float l1 = w.p[1].x, l2 = w.p[0].y, l30 = w.p[28].y, l31 = w.p[29].y;
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+            float lo = acc[m].x;
+            lo = __builtin_fmaf(l30, xp[(2 + 4 * m) >> 1][0], lo);
+            lo = __builtin_fmaf(l31, xp[(1 + 4 * m) >> 1][1], lo);
+            lo = __builtin_fmaf(l1, xp[(33 + 4 * m) >> 1][1], lo);
+            lo = __builtin_fmaf(l2, xp[(34 + 4 * m) >> 1][0], lo);
+            acc[m].x = lo;
+        }
+    }
+    template <int R0, int R1, class XP>
+    __device__ __forceinline__ void right(const XP& xp, const TapPairs& w) {
+#pragma unroll
+        for (int r = R0; r < R1; ++r)
+#pragma unroll
+            for (int m = 0; m < NP; ++m) {
+                const int n = 33 + 4 * m + r;                              // x[2k + 1 + r]: tap r of output k, tap r - 2 of output k + 1
+                if (n & 1) pk_right<1>(acc[m], w.p[r - 1], xp[n >> 1]); else pk_right<0>(acc[m], w.p[r - 1], xp[n >> 1]);
+            }
+    }
+    template <class XP>
+    __device__ __forceinline__ void close(const XP& xp, const TapPairs& w, float (&out)[2 * NP]) {
+        const float l30 = w.p[28].y, l31 = w.p[29].y;
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+            float hi = acc[m].y;
+            hi = __builtin_fmaf(l30, xp[(64 + 4 * m) >> 1][0], hi);
+            hi = __builtin_fmaf(l31, xp[(65 + 4 * m) >> 1][1], hi);
+            out[2 * m] = acc[m].x;
+            out[2 * m + 1] = hi;
+        }
+        // unpinned, the optimiser sinks each output's chain into the branch that later keeps or zeroes it (serial chains)
+#pragma unroll
+        for (int k = 0; k < 2 * NP; ++k) asm volatile("" : "+v"(out[k]));
+    }
+};
 template <int NP>
 __device__ __forceinline__ void taps63_pairs(const f32x2 (&xp)[32 + 2 * NP], const TapPairs& w, float (&out)[2 * NP]) {
-    auto X = [&](int n) -> float { return xp[n >> 1][n & 1]; };
-    const float l0 = w.p[0].x, l1 = w.p[1].x, l2 = w.p[0].y, l30 = w.p[28].y, l31 = w.p[29].y;
-    f32x2 acc[NP];
-#pragma unroll
-    for (int m = 0; m < NP; ++m) {
-        // left wing of the odd output (k + 1 = 2 m + 1): its taps 0 and 1 have no partner
-        float hi = __builtin_fmaf(l0, X(34 + 4 * m), 0.f);
-        hi = __builtin_fmaf(l1, X(33 + 4 * m), hi);
-        acc[m] = f32x2{0.f, hi};
-    }
-#pragma unroll
-    for (int i = 0; i < 30; ++i)
-#pragma unroll
-        for (int m = 0; m < NP; ++m) {
-            const int n = 32 + 4 * m - i;                              // x[2k - i], k = 2 m
-            if (n & 1) pk_left<1>(acc[m], w.p[i], xp[n >> 1]); else pk_left<0>(acc[m], w.p[i], xp[n >> 1]);
-        }
-#pragma unroll
-    for (int m = 0; m < NP; ++m) {
-        // the even output finishes its left wing (taps 30, 31) and opens its right wing (r = 0, 1) alone
-        float lo = acc[m].x;
-        lo = __builtin_fmaf(l30, X(2 + 4 * m), lo);
-        lo = __builtin_fmaf(l31, X(1 + 4 * m), lo);
-        lo = __builtin_fmaf(l1, X(33 + 4 * m), lo);
-        lo = __builtin_fmaf(l2, X(34 + 4 * m), lo);
-        acc[m].x = lo;
-    }
-#pragma unroll
-    for (int r = 2; r < NR; ++r)
-#pragma unroll
-        for (int m = 0; m < NP; ++m) {
-            const int n = 33 + 4 * m + r;                              // x[2k + 1 + r]: tap r of output k, tap r - 2 of output k + 1
-            if (n & 1) pk_right<1>(acc[m], w.p[r - 1], xp[n >> 1]); else pk_right<0>(acc[m], w.p[r - 1], xp[n >> 1]);
-        }
-#pragma unroll
-    for (int m = 0; m < NP; ++m) {
-        // the odd output's last two taps (r = 29, 30)
-        float hi = acc[m].y;
-        hi = __builtin_fmaf(l30, X(64 + 4 * m), hi);
-        hi = __builtin_fmaf(l31, X(65 + 4 * m), hi);
-        out[2 * m] = acc[m].x;
-        out[2 * m + 1] = hi;
-    }
-    // unpinned, the optimiser sinks each output's chain into the branch that later keeps or zeroes it (serial chains)
-#pragma unroll
-    for (int k = 0; k < 2 * NP; ++k) asm volatile("" : "+v"(out[k]));
+    Taps63<NP> t;
+    t.open(xp, w);
+    t.template left<0, 30>(xp, w);
+    t.turn(xp, w);
+    t.template right<2, NR>(xp, w);
+    t.close(xp, w, out);
 }
 
 // The fused kernel (zns_xqt_stream.hip): both stages in ONE launch, pyramid levels never leave LDS.  vqt bank only.

@@ -107,11 +107,8 @@ __device__ __forceinline__ void taps63x8(const float* __restrict__ p0, int pl, c
     const float* __restrict__ p1 = p0 + pl;
     const float* __restrict__ p2 = p1 + pl;
     const float* __restrict__ p3 = p2 + pl;
-    f32x2 xp[40];                // xp[q] = samples (2 q, 2 q + 1) of the thread's 80-sample span
-    // requested in the order of first use: the taps start at the centre of the span (samples 32 .. 47) and walk down
-#pragma unroll
-    for (int hh = 0; hh < 5; ++hh) {
-        const int h = hh == 0 ? 2 : hh == 1 ? 1 : hh == 2 ? 0 : hh;
+    f32x2 xp[40];                // xp[q] = samples (2 q, 2 q + 1) of the thread's 80-sample span; column h = samples 16 h .. 16 h + 15
+    auto column = [&](int h) {
         float4 a = *reinterpret_cast<const float4*>(p0 + 4 * h);
         const float4 b = *reinterpret_cast<const float4*>(p1 + 4 * h);
         const float4 c = *reinterpret_cast<const float4*>(p2 + 4 * h);
@@ -122,8 +119,28 @@ __device__ __forceinline__ void taps63x8(const float* __restrict__ p0, int pl, c
         xp[8 * h + 2] = f32x2{b.x, b.y}; xp[8 * h + 3] = f32x2{b.z, b.w};
         xp[8 * h + 4] = f32x2{c.x, c.y}; xp[8 * h + 5] = f32x2{c.z, c.w};
         xp[8 * h + 6] = f32x2{d.x, d.y}; xp[8 * h + 7] = f32x2{d.z, d.w};
-    }
-    taps63_pairs<4>(xp, w, out);
+    };
+    // All eight pyramid waves ask for their windows right after the step's barrier: 160 ds_read_b128 queue up, and a wave
+    // that waited for all 20 of its own would start ~600 cycles late.  The columns are requested in the order of first use,
+    // each two phases ahead of the taps that need it (the fences keep the compiler from hoisting every read to the top).
+    Taps63<4> t;
+    column(2); column(1);
+    __builtin_amdgcn_sched_barrier(0);
+    column(0);
+    __builtin_amdgcn_sched_barrier(0);
+    t.open(xp, w);                       // samples 33 .. 46
+    t.left<0, 14>(xp, w);                // 19 .. 44 (+ 12)
+    __builtin_amdgcn_sched_barrier(0);
+    column(3);
+    __builtin_amdgcn_sched_barrier(0);
+    t.left<14, 30>(xp, w);               // 3 .. 30 (+ 12)
+    t.turn(xp, w);
+    __builtin_amdgcn_sched_barrier(0);
+    column(4);
+    __builtin_amdgcn_sched_barrier(0);
+    t.right<2, 15>(xp, w);               // 35 .. 47 (+ 12)
+    t.right<15, NR>(xp, w);              // 48 .. 63 (+ 12)
+    t.close(xp, w, out);
 }
 
 struct Args {
@@ -190,19 +207,35 @@ __device__ __forceinline__ void pyramid_role(const Args& P, float* __restrict__ 
     int uj = -j, itj = 0, clipj, ckj;
     item_of(P, b, 0, clip0, ck0);
     clipj = clip0; ckj = ck0;
+    // Per item, not per step: the clip's row, this thread's sample index at step 0 of the item, and the range of steps in
+    // which its eight samples lie wholly inside the clip (two 16-byte loads, nothing to check); the level's first output
+    // index at step 0 likewise.  The step loop then adds u * S0 (a scalar) and compares u with two registers.
+    const float* __restrict__ xrow = P.wav;
+    int ld_i0 = 0, ld_ulo = 1, ld_uhi = 0, oj0 = 0;
+    auto loader_item = [&]() {
+        xrow = P.wav + (long long)clip0 * P.n;
+        ld_i0 = (ck0 * P.chs - P.W) * S0 + 8 * tid;
+        // idx(u) = ld_i0 + u * S0 >= 0  and  idx(u) + 7 < n
+        ld_ulo = ld_i0 >= 0 ? 0 : (-ld_i0 + S0 - 1) / S0;
+        ld_uhi = P.vec0 && it0 < nmine ? (P.n - 8 - ld_i0 >= 0 ? (P.n - 8 - ld_i0) / S0 : -1) : -1;
+    };
+    auto level_item = [&]() { oj0 = (((ckj * P.chs - P.W) * S0) >> j) + obase; };
+    loader_item();
+    level_item();
     const TapPairs& W = P.taps;
     for (int s = 0; s < steps; ++s) {
         const int par = s & 1;
         SQ_STAMP(P, s, 0);
         // ---- level 0: the step's 8 samples of this thread, global -> registers (stored at the end of the step)
         float4 fa = make_float4(0.f, 0.f, 0.f, 0.f), fb = fa;
-        if (it0 < nmine) {
-            const int idx = (ck0 * P.chs + u0 - P.W) * S0 + 8 * tid;
-            const float* __restrict__ x = P.wav + (long long)clip0 * P.n;
-            if (P.vec0 && idx >= 0 && idx + 7 < P.n) {
-                fa = *reinterpret_cast<const float4*>(x + idx);
-                fb = *reinterpret_cast<const float4*>(x + idx + 4);
-            } else if (idx + 7 >= 0 && idx < P.n) {
+        if (u0 >= ld_ulo && u0 <= ld_uhi) {
+            const float* __restrict__ xp = xrow + u0 * S0;               // a scalar base; the lane part is ld_i0
+            fa = *reinterpret_cast<const float4*>(xp + ld_i0);
+            fb = *reinterpret_cast<const float4*>(xp + ld_i0 + 4);
+        } else if (it0 < nmine) {
+            const int idx = ld_i0 + u0 * S0;                             // a clip end, or rows off 16-byte alignment
+            if (idx + 7 >= 0 && idx < P.n) {
+                const float* __restrict__ x = xrow;
                 if (idx >= 0) fa.x = x[idx];
                 if (idx + 1 >= 0 && idx + 1 < P.n) fa.y = x[idx + 1];
                 if (idx + 2 >= 0 && idx + 2 < P.n) fa.z = x[idx + 2];
@@ -218,7 +251,7 @@ __device__ __forceinline__ void pyramid_role(const Args& P, float* __restrict__ 
         if (!idle) {
             float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (uj >= 0 && itj < nmine) {
-                const int o0 = (((ckj * P.chs - P.W) * S0) >> j) + uj * sj + obase;     // first output index in the clip
+                const int o0 = oj0 + uj * sj;                             // first output index in the clip
                 if (o0 + 7 >= 0 && o0 < nout && !(P.dbg & 1)) {
                     float acc[8];
                     taps63x8(lds + src_a + (par ? 4 * src_pl : 0), src_pl, W, acc);
@@ -242,8 +275,8 @@ __device__ __forceinline__ void pyramid_role(const Args& P, float* __restrict__ 
         // ---- level 0: registers -> window 0 of the next step
         *reinterpret_cast<float4*>(lds + ld_a0 + (par ? 0 : 4 * PL_(0))) = fa;
         *reinterpret_cast<float4*>(lds + ld_a1 + (par ? 0 : 4 * PL_(0))) = fb;
-        if (++u0 == P.K) { u0 = 0; ++it0; item_of(P, b, it0, clip0, ck0); }
-        if (++uj == P.K) { uj = 0; ++itj; item_of(P, b, itj, clipj, ckj); }
+        if (++u0 == P.K) { u0 = 0; ++it0; item_of(P, b, it0, clip0, ck0); loader_item(); }
+        if (++uj == P.K) { uj = 0; ++itj; item_of(P, b, itj, clipj, ckj); level_item(); }
         SQ_STAMP(P, s, 3);
         __syncthreads();
         SQ_STAMP(P, s, 4);
@@ -434,20 +467,24 @@ __device__ __forceinline__ void filter_role(const Args& P, float* __restrict__ l
     //   wave 1: octave 1 + octave 6                                              2048 + 512       = 2560
     //   wave 2: octave 2 + octave 5                                              2048 + 512       = 2560
     //   wave 3: octave 3 + row tile 0 of octave 4 + row tile 1 of octave 7      2048 + 512 + 128 = 2688
-    // (both waves that share an octave stage it for themselves: 46 or 304 floats, cheaper than a barrier)
+    // (both waves that share an octave stage it for themselves: 46 or 304 floats, cheaper than a barrier).  Measured
+    // against it (cycle stamps, the younger pyramid wave of each SIMD reaching the barrier): all of octave 7 and row tile 1 of
+    // octave 4 on wave 0: 8850 / 8120 / 8140 / 7920; this split: 8580 / 7940 / 7890 / 8500; octave 4's row tiles on waves 0 / 3
+    // and octave 7's on waves 1 / 2: 7760 / 8670 / 8770 / 7670 -- a slot costs ~1200 cycles of its wave whatever its size.
     constexpr int S1 = WV == 0 ? 7 : WV == 1 ? 6 : WV == 2 ? 5 : 4;
     constexpr int S1_RTM = (WV == 0 || WV == 3) ? 1 : 3;
     constexpr bool HAS_E = WV == 0 || WV == 3;
     constexpr int EO = WV == 0 ? 4 : 7;
+    constexpr int E_RTM = 2;
     float* __restrict__ stgB = stg, * __restrict__ stgS = stg + STG_(WV), * __restrict__ stgE = stg + STG_(WV) + STG_(S1);
     float a0[32], a1[32];
     load_operand<32>(P.fira16 + P.offa16[WV], lane, a0);
     load_operand<32>(P.fira16 + P.offa16[WV] + 32 * 64, lane, a1);
     float c0[NFFT_(S1) / 4], c1[NFFT_(S1) / 4];
-    load_operand<NFFT_(S1) / 4>(P.fira16 + P.offa16[S1], lane, c0);
+    if constexpr (S1_RTM & 1) load_operand<NFFT_(S1) / 4>(P.fira16 + P.offa16[S1], lane, c0);
     if constexpr (S1_RTM & 2) load_operand<NFFT_(S1) / 4>(P.fira16 + P.offa16[S1] + (NFFT_(S1) / 4) * 64, lane, c1);
     float e1[NFFT_(EO) / 4];
-    if constexpr (HAS_E) load_operand<NFFT_(EO) / 4>(P.fira16 + P.offa16[EO] + (NFFT_(EO) / 4) * 64, lane, e1);
+    if constexpr (HAS_E) load_operand<NFFT_(EO) / 4>(P.fira16 + P.offa16[EO] + (E_RTM == 2 ? (NFFT_(EO) / 4) * 64 : 0), lane, e1);
     Oct<WV> OB; Oct<S1> OS; Oct<EO> OE;
     OB.init(P, lane, b); OS.init(P, lane, b); OE.init(P, lane, b);
     // the one filter wave of a SIMD is its youngest wave and loses issue arbitration to the two pyramid waves: give it the
@@ -471,7 +508,7 @@ __device__ __forceinline__ void filter_role(const Args& P, float* __restrict__ l
         if (OB.tile) octave_mma<WV, 3>(P, OB, stgB, lane, a0, a1);
         SQ_STAMP(P, s, 2);
         if (OS.tile) octave_mma<S1, S1_RTM>(P, OS, stgS, lane, c0, c1);
-        if constexpr (HAS_E) { if (OE.tile) octave_mma<EO, 2>(P, OE, stgE, lane, e1, e1); }
+        if constexpr (HAS_E) { if (OE.tile) octave_mma<EO, E_RTM>(P, OE, stgE, lane, e1, e1); }
         OB.advance(P, b); OS.advance(P, b);
         if constexpr (HAS_E) OE.advance(P, b);
         SQ_STAMP(P, s, 3);
