@@ -242,7 +242,8 @@ __device__ __forceinline__ f32x4 lds_ld4(unsigned lds_byte) {
 __device__ __forceinline__ f32x2 lds_ld2(unsigned lds_byte) {
     return *(const __attribute__((address_space(3))) f32x2*)(size_t)lds_byte;
 }
-template <class C, int BOFF>
+// NCT <= CT: the wave's LIVE column tiles (the tiles beyond the row in the last column block are neither read nor multiplied)
+template <class C, int BOFF, int NCT = C::CT>
 __device__ __forceinline__ void compute_stage(unsigned a_addr, const unsigned (&tap)[C::KW],
                                               f32x16 (&acc)[C::MT][C::RT][C::CT]) {
     // steps k = (channel pair, kernel column); the operands of step k + 1 are requested before the MFMAs of step k
@@ -263,7 +264,7 @@ __device__ __forceinline__ void compute_stage(unsigned a_addr, const unsigned (&
 #pragma unroll
         for (int rt = 0; rt < C::RT; ++rt)
 #pragma unroll
-            for (int ct = 0; ct < C::CT; ++ct)
+            for (int ct = 0; ct < NCT; ++ct)
                 bv[rt][ct] = lds_ld(tap[s] + BOFF + (2 * cp * C::PS + rt * C::PCW + ct * 32) * 4);
     };
     fetch(0, a[0], b[0]);
@@ -275,7 +276,7 @@ __device__ __forceinline__ void compute_stage(unsigned a_addr, const unsigned (&
 #pragma unroll
             for (int rt = 0; rt < C::RT; ++rt)
 #pragma unroll
-                for (int ct = 0; ct < C::CT; ++ct)
+                for (int ct = 0; ct < NCT; ++ct)
                     acc[m][rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k & 1][m], b[k & 1][rt][ct], acc[m][rt][ct], 0, 0, 0);
     }
 }
@@ -417,6 +418,9 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
     // wave's 64 columns are padding) skips its multiplies -- it still loads and meets the barriers -- and leaves its SIMD's
     // matrix pipe to the co-resident workgroups
     const bool idle = !C::HET && w0 + wc * C::CT * 32 >= T;
+    // the frequency-domain layouts with several column tiles per wave also drop the DEAD tiles of a partly live wave (cv3
+    // backward-data: 11 column tiles in two blocks of 2 x 3): wave-uniform, the K loop is instantiated per live count
+    const int live_ct = C::HET ? C::CT : (T - (w0 + wc * C::CT * 32) + 31) / 32;
 
     // one stage of the K loop; PAR >= 0: buffer parity known at compile time (an immediate), -1: run-time parity;
     // TAC: the wave kind of the two-kind layout
@@ -442,7 +446,7 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
                 f32x16(&hacc)[4] = *reinterpret_cast<f32x16(*)[4]>(&acc[0][0][0]);
                 compute_stage_het<C, PAR * PBYTES, TA>(a_addr[PAR], tap, hacc);
             } else {
-                compute_stage<C, PAR * PBYTES>(a_addr[PAR], tap, acc);
+                compute_stage<C, PAR * PBYTES, decltype(TAC)::value>(a_addr[PAR], tap, acc);
             }
         } else {
             unsigned tr[C::KW];
@@ -531,8 +535,13 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
             }
         }
         return;
+    } else if constexpr (C::DILMAX > 0 && C::KH == 1 && C::NCC % 2 == 0 && C::CT > 1) {
+        // (TAC carries the live column-tile count here; the barriers inside pair up: same trip counts)
+        if (C::CT >= 3 && live_ct == 2) k_stages(std::integral_constant<int, (C::CT >= 3 ? 2 : C::CT)>{});
+        else if (live_ct == 1) k_stages(std::integral_constant<int, 1>{});
+        else k_stages(std::integral_constant<int, C::CT>{});
     } else {
-        k_stages(std::true_type{});
+        k_stages(std::integral_constant<int, C::CT>{});
     }
 
     // ------------------------------------------------------------------ epilogue

@@ -626,6 +626,10 @@ using FF4 = ConvCfg<128, 128, 1, 9, 1, 4, 1, 1, 1, 1, 12, 8, 1, 1, FDIL, 8>;
 using FF5 = ConvCfg<128, 256, 1, 3, 1, 2, 1, 1, 4, 1, 3, 8, 1, 1, FDIL>;
 using FF6 = ConvCfg<256, 256, 1, 5, 1, 2, 1, 1, 4, 1, 3, 4, 1, 1, FDIL>;
 // narrower variants for short flattened axes (e.g. T = 313 / 626: P = 224 for cv3/cv4, 56..64 for cv5/cv6)
+// cv2 at P = 960 = 5 x 192 (T = 512) or 576 = 3 x 192 (T = 313): 192-column blocks of 4 waves x (1 channel tile x 3 column
+// tiles) fill every SIMD in every block, where the 256-column blocks leave a wave idle in the last one: 1337 -> 1277 us
+using FF2a = ConvCfg<64, 64, 1, 7, 1, 1, 1, 3, 2, 1, 2, 8, 1, 1, FDIL>;
+using FD2a = FF2a;
 using FF3a = ConvCfg<64, 128, 1, 5, 1, 4, 1, 1, 1, 1, 8, 8, 1, 1, FDIL, 4>;    // 7 column tiles, 8 waves
 using FF4a = ConvCfg<128, 128, 1, 9, 1, 4, 1, 1, 1, 1, 8, 8, 1, 1, FDIL, 4>;
 using FF5a = ConvCfg<128, 256, 1, 3, 1, 2, 1, 1, 4, 1, 2, 16, 1, 1, FDIL>;
@@ -635,7 +639,10 @@ using FD4a = FF4a;
 using FD5a = ConvCfg<256, 128, 1, 3, 1, 1, 1, 1, 4, 1, 2, 16, 1, 1, FDIL>;
 using FD6a = FF6a;
 using FD2 = FF2;
-using FD3 = ConvCfg<128, 64, 1, 5, 1, 2, 1, 1, 1, 1, 11, 8, 1, 1, FDIL>;
+// cv3 backward-data (2 channel tiles x 11 column tiles): two blocks of 192 columns, 4 waves x (1 channel tile x 3 column
+// tiles) like FF2a, the dead twelfth column tile skipped (conv_core's live-tile K loop): 752 -> 683 us against the 11-wave
+// one-block layout, whose SIMDs carried 3 / 3 / 3 / 2 waves
+using FD3 = ConvCfg<128, 64, 1, 5, 1, 1, 1, 3, 2, 1, 2, 8, 1, 1, FDIL>;
 using FD4 = FF4;
 using FD5 = ConvCfg<256, 128, 1, 3, 1, 1, 1, 1, 4, 1, 3, 16, 1, 1, FDIL>;
 using FD6 = FF6;
@@ -983,7 +990,9 @@ template <class T> struct cfg_tag { typedef T type; };
 template <class Fn>
 static int with_cfg(const ConvArgs& a, int transposed, Fn&& f) {
     switch (fft_layer_of(a)) {
-        case 2: return transposed ? f(cfg_tag<FD2>{}) : f(cfg_tag<FF2>{});
+        case 2:
+            if (use_narrow<FF2, FF2a>(a)) return transposed ? f(cfg_tag<FD2a>{}) : f(cfg_tag<FF2a>{});
+            return transposed ? f(cfg_tag<FD2>{}) : f(cfg_tag<FF2>{});
         case 3:
             if (transposed) return use_narrow<FD3, FD3a>(a) ? f(cfg_tag<FD3a>{}) : f(cfg_tag<FD3>{});
             return use_narrow<FF3, FF3a>(a) ? f(cfg_tag<FF3a>{}) : f(cfg_tag<FF3>{});
