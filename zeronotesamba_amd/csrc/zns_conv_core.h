@@ -537,9 +537,11 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
         return;
     } else if constexpr (C::DILMAX > 0 && C::KH == 1 && C::NCC % 2 == 0 && C::CT > 1) {
         // (TAC carries the live column-tile count here; the barriers inside pair up: same trip counts)
-        if (C::CT >= 3 && live_ct == 2) k_stages(std::integral_constant<int, (C::CT >= 3 ? 2 : C::CT)>{});
+        if (live_ct >= C::CT) k_stages(std::integral_constant<int, C::CT>{});
         else if (live_ct == 1) k_stages(std::integral_constant<int, 1>{});
-        else k_stages(std::integral_constant<int, C::CT>{});
+        else if (C::CT > 2 && live_ct == 2) k_stages(std::integral_constant<int, (C::CT > 2 ? 2 : C::CT)>{});
+        else if (C::CT > 3 && live_ct == 3) k_stages(std::integral_constant<int, (C::CT > 3 ? 3 : C::CT)>{});
+        else k_stages(std::integral_constant<int, (C::CT > 4 ? 4 : C::CT)>{});
     } else {
         k_stages(std::integral_constant<int, C::CT>{});
     }

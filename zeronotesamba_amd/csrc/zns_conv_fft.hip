@@ -630,6 +630,10 @@ using FF6 = ConvCfg<256, 256, 1, 5, 1, 2, 1, 1, 4, 1, 3, 4, 1, 1, FDIL>;
 // tiles) fill every SIMD in every block, where the 256-column blocks leave a wave idle in the last one: 1337 -> 1277 us
 using FF2a = ConvCfg<64, 64, 1, 7, 1, 1, 1, 3, 2, 1, 2, 8, 1, 1, FDIL>;
 using FD2a = FF2a;
+// (measured and not kept, same step: 320-column blocks of 4 waves x (1 x 5) for cv2: 1304 us against 1265; 4-wave blocks
+// of (2 x 3) / (1 x 3) tiles per wave for cv5 forward / backward-data: 449 / 450 us against 436 / 434; cv3 forward as
+// 4 waves x (1 x 3) or (2 x 3): 749 / 769 us against the two-kind layout's 699; cv3 backward-data with 16 input channels per
+// stage: 746 us against 683)
 using FF3a = ConvCfg<64, 128, 1, 5, 1, 4, 1, 1, 1, 1, 8, 8, 1, 1, FDIL, 4>;    // 7 column tiles, 8 waves
 using FF4a = ConvCfg<128, 128, 1, 9, 1, 4, 1, 1, 1, 1, 8, 8, 1, 1, FDIL, 4>;
 using FF5a = ConvCfg<128, 256, 1, 3, 1, 2, 1, 1, 4, 1, 2, 16, 1, 1, FDIL>;
@@ -991,6 +995,7 @@ template <class Fn>
 static int with_cfg(const ConvArgs& a, int transposed, Fn&& f) {
     switch (fft_layer_of(a)) {
         case 2:
+            // (a tie -- T = 313: P = 672, 768 padded columns either way -- stays with the 256-column blocks: 993 us against 1006)
             if (use_narrow<FF2, FF2a>(a)) return transposed ? f(cfg_tag<FD2a>{}) : f(cfg_tag<FF2a>{});
             return transposed ? f(cfg_tag<FD2>{}) : f(cfg_tag<FF2>{});
         case 3:
