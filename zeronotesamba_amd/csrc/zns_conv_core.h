@@ -151,7 +151,7 @@ struct CoreArgs {
 // NWL = number of waves that issue the DMA pieces (all of them, or only the youngest wave of every SIMD: see conv_core)
 template <class C>
 struct PatchPlan {
-    // first loader wave (the 11-wave cv3 backward-data layout measured 2 % slower with four loaders: all of its waves load)
+    // first loader wave (round 3's 11-wave cv3 backward-data layout measured 2 % slower with four loaders: NW % 4 != 0 -> all load)
     static constexpr int LW0 = C::HET ? C::HET : (C::DILMAX > 0 && C::NW >= 8 && C::NW % 4 == 0) ? C::NW - 4 : 0;
     static constexpr int NWL = C::NW - LW0;
     static constexpr int NPI = (C::PATCH / 64 + NWL - 1) / NWL;       // 4-byte pieces per loader wave (16-byte mode uses a quarter)
@@ -414,7 +414,7 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
 #pragma unroll
     for (int s = 0; s < C::KW; ++s) asm volatile("" : "+v"(tap[s]));
     constexpr int PBYTES = C::PATCH * 4;
-    // a wave whose column tiles all lie beyond the row (the last column block of cv2: P = 960 = 3 x 256 + 192, the fourth
+    // a wave whose column tiles all lie beyond the row (the 256-column cv2 layout at P = 960 = 3 x 256 + 192: the fourth
     // wave's 64 columns are padding) skips its multiplies -- it still loads and meets the barriers -- and leaves its SIMD's
     // matrix pipe to the co-resident workgroups
     const bool idle = !C::HET && w0 + wc * C::CT * 32 >= T;
