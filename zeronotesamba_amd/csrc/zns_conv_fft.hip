@@ -584,15 +584,24 @@ __global__ void __launch_bounds__(128) wgrad_spec_reduce_kernel(const float* __r
         float cr[FF], cim[FF];
         const float* sp0 = slab + (size_t)br * FS * KS * per_ks;           // uniform: scalar base + 32-bit lane offset
         const size_t slot = (size_t)KS * per_ks;
+        // Slot planes through a buffer descriptor per block of eight frequencies (base = the block's first plane, lane offset =
+        // the element, scalar offset = plane and split): with plain pointers the 96 plane addresses of the unrolled loops are
+        // loop invariants of the split loop, 192 scalar registers the kernel does not have -- it spilled 236 of them to vector
+        // lanes and moved them back and forth with 237 v_readlane + 236 v_writelane per tap.
+        const unsigned slot_b = (unsigned)(slot * sizeof(float)), ks_b = (unsigned)(per_ks * sizeof(float));
 #pragma unroll
         for (int f0 = 0; f0 < FF; f0 += 8) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) cr[f0 + j] = cim[f0 + j] = 0.f;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(sp0 + (size_t)(3 * f0) * slot), 0, 0x7fffffff, 0x00020000);
             for (int k = 0; k < KS; ++k) {
-                const float* sp = sp0 + (size_t)k * per_ks + (size_t)(3 * f0) * slot;
+                unsigned sb = slot_b;
+                asm volatile("" : "+s"(sb));                 // the plane offsets are computed per trip, not kept
+                const unsigned kb = (unsigned)k * ks_b;
                 float r[24];
 #pragma unroll
-                for (int j = 0; j < 24; ++j) r[j] = (sp + (size_t)j * slot)[eoff];
+                for (int j = 0; j < 24; ++j) r[j] = spec_load(rs, eoff * 4u, (unsigned)j * sb + kb);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float r1 = r[3 * j], r2 = r[3 * j + 1], r3 = r[3 * j + 2];
