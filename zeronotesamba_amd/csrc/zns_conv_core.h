@@ -127,6 +127,11 @@ struct CoreArgs {
     int ncb;               // column blocks
     int dil, F;            // DILMAX > 0 only: tap spacing, number of frequency slots (weights indexed by (branch, f))
     int ipw;               // two-kind layout with EPI_SEP: consecutive samples per workgroup (>= 1; the grid shrinks accordingly)
+    // split of the input-channel loop over `ks` workgroups (0 / 1: none): the configuration's CIN is then ONE part's channels,
+    // `cin_full` the tensor's (x, packed weights); part k writes its raw sums to dx + k * N * COUT * H * T (EPI 1, no mask,
+    // no unpool) and conv_split_finish_kernel adds the parts in order and applies the layer's epilogue
+    int ks, cin_full;
+    int kparts;            // consecutive CIN-channel parts one workgroup runs through (>= 1): the split is cin_full / (CIN * kparts) ways
     // EPI 0
     Ptr2 bias;
     float* y;
@@ -342,9 +347,14 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
     const int rb = bid % (C::H / C::RB);
     bid /= (C::H / C::RB);
     const int cob = bid % (C::COUT / C::COB);
+    bid /= (C::COUT / C::COB);
+    const int ksn = (!C::HET && A.ks > 1) ? A.ks : 1;
+    const int ksi = bid % ksn;
+    bid /= ksn;
+    const int cinf = (!C::HET && A.cin_full > 0) ? A.cin_full : C::CIN;
     // several consecutive samples per workgroup (two-kind layout, host guarantees one block per sample then)
     const int ipw = (C::HET && C::EPI_SEP && A.ipw > 1) ? A.ipw : 1;
-    int n = (bid / (C::COUT / C::COB)) * ipw;
+    int n = bid * ipw;
     const int nitems = ipw > 1 ? (A.N - n < ipw ? A.N - n : ipw) : 1;
     auto branch_of = [&](int nn) { return C::DILMAX ? nn / (A.B * A.F) : nn / A.B; };
     const int br = branch_of(n);
@@ -353,10 +363,13 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
     const int h0 = rb * C::RB, w0 = cb * C::WB;
     const int T = A.T;
 
-    auto x_of = [&](int nn) { return A.x + (size_t)nn * C::CIN * C::H * T; };
+    const int kp = (ksn > 1 && A.kparts > 1) ? A.kparts : 1;       // CIN-channel parts this workgroup accumulates
+    int part = ksi * kp;                                           // the current one
+    auto x_of = [&](int nn) { return A.x + ((size_t)nn * cinf + (size_t)part * C::CIN) * C::H * T; };
     auto w_of = [&](int nn) {
         const int b2 = branch_of(nn), widx = C::DILMAX ? b2 * A.F + nn % A.F : b2;
-        return A.wpk + (size_t)widx * C::COUT * C::CIN * C::KH * C::KW + (size_t)cob * C::NST * C::SLAB;
+        return A.wpk + (size_t)widx * C::COUT * cinf * C::KH * C::KW + (size_t)cob * (cinf / C::CK * C::KH) * C::SLAB +
+               (size_t)part * C::NST * C::SLAB;
     };
     const float* xn = x_of(n);
     const float* wbase = w_of(n);
@@ -542,6 +555,16 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
         else if (C::CT > 2 && live_ct == 2) k_stages(std::integral_constant<int, (C::CT > 2 ? 2 : C::CT)>{});
         else if (C::CT > 3 && live_ct == 3) k_stages(std::integral_constant<int, (C::CT > 3 ? 3 : C::CT)>{});
         else k_stages(std::integral_constant<int, (C::CT > 4 ? 4 : C::CT)>{});
+    } else if constexpr (C::KH == 1 && C::NCC % 2 == 0) {
+        // a K-split workgroup runs through its kp parts like the two-kind layout through its items: the next part's first slab
+        // and patch are requested during the current part's last stage (NST is even: buffers 0 are free again)
+        for (int q = 0; q < kp; ++q) {
+            has_next = q + 1 < kp;
+            if (has_next) { ++part; xn_next = x_of(n); wbase_next = w_of(n); }
+            k_stages(std::integral_constant<int, C::CT>{});
+            if (has_next) { xn = xn_next; wbase = wbase_next; }
+        }
+        has_next = false;
     } else {
         k_stages(std::integral_constant<int, C::CT>{});
     }
@@ -586,8 +609,9 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
         }
     } else {
         const int pp = A.prev_pool;
+        float* const dxp = A.dx + (size_t)ksi * A.N * C::COUT * C::H * T;      // (a split part's own slab)
         if constexpr (C::LDS_BYTES >= C::NW * 32 * ETS * 4) {
-            if (A.xmask == nullptr && pp == 1 && (T & 3) == 0 && (reinterpret_cast<uintptr_t>(A.dx) & 15) == 0) {
+            if (A.xmask == nullptr && pp == 1 && (T & 3) == 0 && (reinterpret_cast<uintptr_t>(dxp) & 15) == 0) {
                 __syncthreads();                           // every wave is done with the last stage's operands
                 float* tb = smem + wid * (32 * ETS);
 #pragma unroll
@@ -598,7 +622,7 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
                         for (int ct = 0; ct < C::CT; ++ct) {
                             const int co0 = cob * C::COB + (wm * C::MT + m) * 32;
                             const int row = h0 + wr * C::RT + rt;
-                            store_tile_t(tb, acc[m][rt][ct], A.dx + (((size_t)n * C::COUT + co0) * C::H + row) * T,
+                            store_tile_t(tb, acc[m][rt][ct], dxp + (((size_t)n * C::COUT + co0) * C::H + row) * T,
                                          (size_t)C::H * T, w0 + (wc * C::CT + ct) * 32, T, lane);
                         }
                 return;
@@ -623,9 +647,9 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
                         if (pp > 1) {
                             const int am = A.prev_argmax[o];
                             const size_t base = (((size_t)n * C::COUT + co) * C::H + row) * pp * T + col;
-                            for (int a = 0; a < pp; ++a) A.dx[base + (size_t)a * T] = (a == am) ? g : 0.f;
+                            for (int a = 0; a < pp; ++a) dxp[base + (size_t)a * T] = (a == am) ? g : 0.f;
                         } else {
-                            A.dx[o] = g;
+                            dxp[o] = g;
                         }
                     }
                 }

@@ -44,6 +44,24 @@ using F7s = ConvCfg<256, 128, 1, 23, 1, 1, 1, 1, 4, 1, 1, 4, 1, 0>;
 using F8s = ConvCfg<128, 128, 1, 25, 1, 1, 1, 1, 4, 1, 1, 4, 1, 0>;
 using D7s = ConvCfg<128, 256, 1, 23, 1, 2, 1, 1, 4, 1, 1, 2, 1, 1>;
 using D8s = ConvCfg<128, 128, 1, 25, 1, 1, 1, 1, 4, 1, 1, 4, 1, 1>;
+// cv7 / cv8 with the input-channel loop SPLIT over workgroups (K-split): the configuration's CIN is an eighth of the layer's;
+// a workgroup runs through 8 / ks consecutive eighths, the ks workgroups of a tile write raw partial sums and
+// conv_split_finish_kernel adds them in a fixed order and applies the layer's epilogue.  Why: a 32 x 32 tile's whole K loop on
+// one SIMD is the unit of these launches, and there are few of them -- T = 512: 256 workgroups of 8 waves = one per CU with its
+// 94 KB of operands (matrix pipes 0.62-0.78 busy); T = 313: 160 workgroups on 256 CUs; the batch-of-one fine-tune step: 59.
+// With 2 input channels per stage the operands are 48 KB: three workgroups per CU, several K loops' barriers interleaved.
+// `*kP` are the same shapes with the layer's full CIN: the layout the operand is packed in (never instantiated as a kernel).
+constexpr int KSPLIT_PARTS = 8;
+using F7k = ConvCfg<256 / KSPLIT_PARTS, 128, 1, 23, 1, 1, 1, 1, 4, 1, 2, 2, 1, 1>;
+using F8k = ConvCfg<128 / KSPLIT_PARTS, 128, 1, 25, 1, 1, 1, 1, 4, 1, 2, 2, 1, 1>;
+using D7k = ConvCfg<128 / KSPLIT_PARTS, 256, 1, 23, 1, 1, 1, 1, 4, 1, 2, 2, 1, 1>;
+using D8k = F8k;
+using F7kP = ConvCfg<256, 128, 1, 23, 1, 1, 1, 1, 4, 1, 2, 2, 1, 1>;
+using F8kP = ConvCfg<128, 128, 1, 25, 1, 1, 1, 1, 4, 1, 2, 2, 1, 1>;
+using D7kP = ConvCfg<128, 256, 1, 23, 1, 1, 1, 1, 4, 1, 2, 2, 1, 1>;
+using D8kP = F8kP;
+static_assert(F7k::NCC % 2 == 0 && F8k::NCC % 2 == 0 && D7k::NCC % 2 == 0, "parts are chained like items: even stage counts");
+
 // true when the wide tiles would leave most CUs without a workgroup
 template <class Wide>
 static bool few_workgroups(const ConvArgs& a) {
@@ -94,7 +112,12 @@ size_t mfma_workspace_bytes(const ConvArgs& a) {
         default: return 0;
     }
     const size_t pk = (packed_bytes(a) + 255) & ~(size_t)255;
-    return pk > slab ? pk : slab;
+    size_t need = pk > slab ? pk : slab;
+    if (layer_of(a) >= 7) {       // the K-split forward / backward-data: packed operand + partial sums (COUT = max(cin, cout))
+        const size_t part = (size_t)KSPLIT_PARTS * a.nbr * a.B * (a.cin > a.cout ? a.cin : a.cout) * a.T * sizeof(float);
+        if (pk + part > need) need = pk + part;
+    }
+    return need;
 }
 
 template <class C>
@@ -159,6 +182,125 @@ static int launch_core(const ConvArgs& a, CoreArgs A, Ptr2 w, int transposed, co
     return ZNS_OK;
 }
 
+// The partial sums of a K-split launch, [ks][N][COUT][T] (H = 1), added in the order of the parts, then the epilogue conv_core
+// would have run on its accumulators: MODE 0 forward (bias, ReLU, dropout -- cv7 / cv8 have no pooling), MODE 1 backward-data
+// (ReLU / dropout mask of the previous layer, max-unpool over its `pp` rows).
+struct SplitFin {
+    Ptr2 bias;
+    float* out;
+    const float* xmask;
+    const uint8_t* prev_argmax;
+    uint32_t thresh, seed;
+    float inv_keep;
+    int layer, B, cout, T, pp, ks;
+};
+template <int MODE>
+__global__ void __launch_bounds__(256) conv_split_finish_kernel(const float* __restrict__ slab, size_t per, SplitFin F) {
+    const size_t o = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= per) return;
+    float s = slab[o];
+    for (int k = 1; k < F.ks; ++k) s += slab[(size_t)k * per + o];
+    const int col = (int)(o % F.T);
+    const size_t nc = o / F.T;                      // n * cout + co
+    const int co = (int)(nc % F.cout), n = (int)(nc / F.cout);
+    if (MODE == 0) {
+        const int br = n / F.B, b_in_br = n - br * F.B;
+        float v = relu_nan(s + F.bias.p[br][co]);
+        if (F.thresh) {
+            const uint64_t idx = ((uint64_t)b_in_br * F.cout + co) * F.T + col;
+            v = drop_apply(drop_keep(layer_seed(F.seed, F.layer, br), idx, F.thresh), v, F.inv_keep);
+        }
+        F.out[o] = v;
+    } else {
+        float g = s;
+        if (F.xmask) g = (F.xmask[o] != 0.f) ? g * F.inv_keep : 0.f;
+        if (F.pp > 1) {
+            const int am = F.prev_argmax[o];
+            const size_t base = nc * F.pp * F.T + col;
+            for (int a = 0; a < F.pp; ++a) F.out[base + (size_t)a * F.T] = (a == am) ? g : 0.f;
+        } else {
+            F.out[o] = g;
+        }
+    }
+}
+
+static int ksplit_mode() {
+    static const int m = [] { const char* e = getenv("ZNS_KSPLIT"); return e ? atoi(e) : -1; }();
+    return m;      // -1: automatic; 0: off; 2 / 4 / 8: forced split
+}
+// How many ways the K loop of a cv7 / cv8 launch is split (1 = the unsplit kernels): all eight, or not at all -- and the
+// choice follows T alone, never the batch: the summation order of a clip's activations must not depend on the batch it is
+// in (tests/test_gpu_fullsize.py: a batch of 80 equals its chunks of 16 bit for bit).  Rows whose 64-column tiles come in
+// multiples of eight (T = 512: 8 per clip, 256 for the reference's batch of 16 pairs = one per CU) stay unsplit: measured
+// per step, unsplit / 2 / 4 / 8 ways, T = 512: 23.23 / 23.12 / 23.25 / 23.23 ms (the split kernels' 5-20 % are what the finish
+// launches cost: cv7 backward-data writes 134 MB of unpooled rows in any case); T = 313 (5 tiles per clip, 160 per batch):
+// 16.90 / 16.77 / 16.74 / 16.73 ms; the batch-of-one fine-tune step (T = 1876, 30 tiles): 7.24 / 7.04 / 7.02 / 6.97 ms.
+// The split sums are also the more accurate ones (eight chains of an eighth of the terms: 3.5e-7 against 9.6e-7 rms of a
+// float64 convolution) -- which moves them AWAY from the float32 CPU oracle, whose own chain errs like the unsplit kernel's:
+// at T = 512 the full-size oracle test's worst gradient read 1.01e-4 of its norm with the split against 6.2e-5 without.
+// ZNS_KSPLIT=0 / 2 / 4 / 8 overrides (tuning).
+template <class C>
+static int ksplit_ways(const ConvArgs& a) {
+    if (a.H != 1) return 1;
+    const int m = ksplit_mode();
+    if (m == 0) return 1;
+    if (m == 2 || m == 4 || m == 8) return m;
+    return ceil_div(a.T, C::WB) % 8 == 0 ? 1 : KSPLIT_PARTS;
+}
+template <class C>
+static size_t ksplit_slab_bytes(const ConvArgs& a) {
+    return (size_t)KSPLIT_PARTS * a.nbr * a.B * C::COUT * a.T * sizeof(float);
+}
+
+// C: the part configuration; CP: its full-CIN twin (packing layout); fin: the finish kernel's arguments (out / masks set)
+template <class C, class CP, int MODE>
+static int launch_split(const ConvArgs& a, const float* x, Ptr2 w, int transposed, const float* wpk, SplitFin F, int ks,
+                        void* ws, size_t ws_bytes, hipStream_t st) {
+    static_assert(C::EPI == 1 && C::KH == 1 && C::H == 1 && CP::CIN == C::CIN * KSPLIT_PARTS && same_pack_layout<C, C>(), "split cfg");
+    const size_t pk = (packed_bytes(a) + 255) & ~(size_t)255;
+    const size_t need = pk + ksplit_slab_bytes<C>(a);
+    if (ws_bytes < need) { set_error("conv (K-split): workspace %zu < %zu", ws_bytes, need); return ZNS_ERR_WORKSPACE; }
+    int rc = ZNS_OK;
+    if (wpk == nullptr) {
+        rc = pack_for<CP>(a, w, (float*)ws, transposed, st);
+        if (rc) return rc;
+        wpk = (const float*)ws;
+    }
+    float* slab = (float*)((char*)ws + pk);
+    rc = set_lds<C>(conv_core<C>);
+    if (rc) return rc;
+    CoreArgs A{};
+    A.x = x;
+    A.wpk = wpk;
+    A.dx = slab;
+    A.xmask = nullptr;
+    A.inv_keep = 1.f;
+    A.prev_pool = 1;
+    A.B = a.B;
+    A.T = a.T;
+    A.N = a.nbr * a.B;
+    A.ncb = ceil_div(a.T, C::WB);
+    A.ks = ks;
+    A.kparts = KSPLIT_PARTS / ks;
+    A.cin_full = CP::CIN;
+    const long long blocks = (long long)A.N * A.ncb * (C::COUT / C::COB) * ks;
+    const bool probe = probe_match(transposed ? 1 : 0, a.cin, a.cout, a.kh);
+    const int slot = probe ? g_probe.count % g_probe.n : 0;
+    if (probe) ZNS_HIP(hipEventRecord(g_probe.start[slot], st));
+    hipLaunchKernelGGL(conv_core<C>, dim3((unsigned)blocks), dim3(C::NT), C::LDS_BYTES, st, A);
+    ZNS_LAUNCH_CHECK();
+    if (probe) { ZNS_HIP(hipEventRecord(g_probe.stop[slot], st)); ++g_probe.count; }
+    const size_t per = (size_t)A.N * C::COUT * a.T;
+    F.B = a.B;
+    F.cout = C::COUT;
+    F.T = a.T;
+    F.ks = ks;
+    hipLaunchKernelGGL(conv_split_finish_kernel<MODE>, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st,
+                       (const float*)slab, per, F);
+    ZNS_LAUNCH_CHECK();
+    return ZNS_OK;
+}
+
 int mfma_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, uint8_t* argmax, float drop_p,
              uint32_t seed, int layer, const float* wpk, void* ws, size_t ws_bytes, hipStream_t st) {
     CoreArgs A{};
@@ -177,11 +319,22 @@ int mfma_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, uin
         case 5: return launch_core<F5>(a, A, w, 0, wpk, ws, ws_bytes, st);
         case 6: return launch_core<F6>(a, A, w, 0, wpk, ws, ws_bytes, st);
         case 7:
-            if (few_workgroups<F7>(a)) return launch_core<F7s>(a, A, w, 0, wpk, ws, ws_bytes, st);
-            return launch_core<F7>(a, A, w, 0, wpk, ws, ws_bytes, st);
-        case 8:
+        case 8: {
+            const bool l7 = layer_of(a) == 7;
+            const int ks = l7 ? ksplit_ways<F7k>(a) : ksplit_ways<F8k>(a);
+            if (ks > 1) {
+                SplitFin F{};
+                F.bias = bias; F.out = y; F.thresh = A.thresh; F.seed = seed; F.inv_keep = A.inv_keep; F.layer = layer; F.pp = 1;
+                return l7 ? launch_split<F7k, F7kP, 0>(a, x, w, 0, wpk, F, ks, ws, ws_bytes, st)
+                          : launch_split<F8k, F8kP, 0>(a, x, w, 0, wpk, F, ks, ws, ws_bytes, st);
+            }
+            if (l7) {
+                if (few_workgroups<F7>(a)) return launch_core<F7s>(a, A, w, 0, wpk, ws, ws_bytes, st);
+                return launch_core<F7>(a, A, w, 0, wpk, ws, ws_bytes, st);
+            }
             if (few_workgroups<F8>(a)) return launch_core<F8s>(a, A, w, 0, wpk, ws, ws_bytes, st);
             return launch_core<F8>(a, A, w, 0, wpk, ws, ws_bytes, st);
+        }
     }
     return ZNS_ERR_ARG;
 }
@@ -202,11 +355,22 @@ int mfma_dgrad(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, const floa
         case 5: return launch_core<D5>(a, A, w, 1, wpk, ws, ws_bytes, st);
         case 6: return launch_core<D6>(a, A, w, 1, wpk, ws, ws_bytes, st);
         case 7:
-            if (few_workgroups<D7>(a)) return launch_core<D7s>(a, A, w, 1, wpk, ws, ws_bytes, st);
-            return launch_core<D7>(a, A, w, 1, wpk, ws, ws_bytes, st);
-        case 8:
+        case 8: {
+            const bool l7 = layer_of(a) == 7;
+            const int ks = l7 ? ksplit_ways<D7k>(a) : ksplit_ways<D8k>(a);
+            if (ks > 1) {
+                SplitFin F{};
+                F.out = dx; F.xmask = x; F.inv_keep = inv_keep; F.prev_argmax = prev_argmax; F.pp = prev_pool;
+                return l7 ? launch_split<D7k, D7kP, 1>(a, dz, w, 1, wpk, F, ks, ws, ws_bytes, st)
+                          : launch_split<D8k, D8kP, 1>(a, dz, w, 1, wpk, F, ks, ws, ws_bytes, st);
+            }
+            if (l7) {
+                if (few_workgroups<D7>(a)) return launch_core<D7s>(a, A, w, 1, wpk, ws, ws_bytes, st);
+                return launch_core<D7>(a, A, w, 1, wpk, ws, ws_bytes, st);
+            }
             if (few_workgroups<D8>(a)) return launch_core<D8s>(a, A, w, 1, wpk, ws, ws_bytes, st);
             return launch_core<D8>(a, A, w, 1, wpk, ws, ws_bytes, st);
+        }
     }
     return ZNS_ERR_ARG;
 }
@@ -226,10 +390,12 @@ int mfma_pack_layout(const ConvArgs& a, int transposed) {
         case 11: return pack_layout_id<D5>(2, 1);
         case 12: return pack_layout_id<F6>(2, 0);
         case 13: return pack_layout_id<D6>(2, 1);
-        case 14: return pack_layout_id<F7>(2, 0);
-        case 15: return pack_layout_id<D7>(2, 1);
-        case 16: return pack_layout_id<F8>(2, 0);
-        case 17: return pack_layout_id<D8>(2, 1);
+        // cv7 / cv8: the K-split kernels stream 2-channel stages, the unsplit ones 4 (2 for cv7 backward-data): the operand's
+        // layout follows the choice the launch will make for this geometry
+        case 14: return ksplit_ways<F7k>(a) > 1 ? pack_layout_id<F7kP>(2, 0) : pack_layout_id<F7>(2, 0);
+        case 15: return ksplit_ways<D7k>(a) > 1 ? pack_layout_id<D7kP>(2, 1) : pack_layout_id<D7>(2, 1);
+        case 16: return ksplit_ways<F8k>(a) > 1 ? pack_layout_id<F8kP>(2, 0) : pack_layout_id<F8>(2, 0);
+        case 17: return ksplit_ways<D8k>(a) > 1 ? pack_layout_id<D8kP>(2, 1) : pack_layout_id<D8>(2, 1);
     }
     return 0;
 }
@@ -246,10 +412,10 @@ int mfma_pack(const ConvArgs& a, Ptr2 w, int transposed, float* dst, hipStream_t
         case 11: return pack_for<D5>(a, w, dst, 1, st);
         case 12: return pack_for<F6>(a, w, dst, 0, st);
         case 13: return pack_for<D6>(a, w, dst, 1, st);
-        case 14: return pack_for<F7>(a, w, dst, 0, st);
-        case 15: return pack_for<D7>(a, w, dst, 1, st);
-        case 16: return pack_for<F8>(a, w, dst, 0, st);
-        case 17: return pack_for<D8>(a, w, dst, 1, st);
+        case 14: return ksplit_ways<F7k>(a) > 1 ? pack_for<F7kP>(a, w, dst, 0, st) : pack_for<F7>(a, w, dst, 0, st);
+        case 15: return ksplit_ways<D7k>(a) > 1 ? pack_for<D7kP>(a, w, dst, 1, st) : pack_for<D7>(a, w, dst, 1, st);
+        case 16: return ksplit_ways<F8k>(a) > 1 ? pack_for<F8kP>(a, w, dst, 0, st) : pack_for<F8>(a, w, dst, 0, st);
+        case 17: return ksplit_ways<D8k>(a) > 1 ? pack_for<D8kP>(a, w, dst, 1, st) : pack_for<D8>(a, w, dst, 1, st);
     }
     return ZNS_ERR_ARG;
 }
