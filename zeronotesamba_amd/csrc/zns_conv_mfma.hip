@@ -225,8 +225,8 @@ __global__ void __launch_bounds__(256) conv_split_finish_kernel(const float* __r
 }
 
 static int ksplit_mode() {
-    static const int m = [] { const char* e = getenv("ZNS_KSPLIT"); return e ? atoi(e) : -1; }();
-    return m;      // -1: automatic; 0: off; 2 / 4 / 8: forced split
+    const char* e = getenv("ZNS_KSPLIT");          // read per call: a test compares the two paths in one process
+    return e ? atoi(e) : -1;                        // -1: automatic; 0: off; 2 / 4 / 8: forced split
 }
 // How many ways the K loop of a cv7 / cv8 launch is split (1 = the unsplit kernels): all eight, or not at all -- and the
 // choice follows T alone, never the batch: the summation order of a clip's activations must not depend on the batch it is
