@@ -19,6 +19,24 @@ extern "C" {
  * launch the family a validation test selected on the Python thread).  Returns the previous value. */
 int zns_set_impl(int impl);
 
+/* Tuning and diagnostic knobs of tests/ and tools/ (process-global, like zns_set_impl).  The library reads NO environment
+ * variable: a stray variable in a training job cannot change a summation order or skip a store.  Every key's default (0,
+ * KSPLIT: -1) is the product behaviour.  zns_test_set_tuning returns ZNS_OK or ZNS_ERR_ARG (unknown key). */
+enum {
+    ZNS_TUNE_KSPLIT = 0,      /* cv7 / cv8 input-channel split: -1 by the rule of T (default), 0 never, 2 / 4 / 8 forced */
+    ZNS_TUNE_IPW,             /* two-kind spectral layout: (sample, slot) items per workgroup, 0 = chosen by the launcher */
+    ZNS_TUNE_XQT_PLAN,        /* per-stage pyramid: chain lengths as decimal digits (223 = chains of 2, 2, 3 levels), 0 = default */
+    ZNS_TUNE_XQT_LDS_PAD,     /* exact pyramid: pad the chain kernel's LDS to this many KiB (caps occupancy) */
+    ZNS_TUNE_XQT_TPW,         /* per-stage filter bank: tiles per wave, 0 = default */
+    ZNS_TUNE_XQT_CHUNKS,      /* fused generate_XQT kernel: runs a clip is cut into, 0 = default */
+    ZNS_TUNE_XQT_DBG,         /* fused kernel: phase-skipping bits (WRONG RESULTS: timing diagnosis only) */
+    ZNS_TUNE_XQT_STAMPS,      /* fused kernel: record s_memtime stamps of workgroup 0 (zns_xqt_debug_stamps) */
+    ZNS_TUNE_WIN128,          /* cv3 / cv4 spectral window: 0 by the launcher's rule, 1 force 128-point, -1 force 64-point */
+    ZNS_TUNE_COUNT
+};
+int zns_test_set_tuning(int key, int value);
+int zns_test_get_tuning(int key);
+
 /* One probe per process: arming while a probe is armed, or disarming from a thread other than the
  * one that armed it, returns ZNS_ERR_ARG.
  * Measurement hook for bench.py: record hipEvents immediately around the MAIN kernel of the next
@@ -37,7 +55,7 @@ int zns_xqt_host_bank(int mode, int* n_fft8, float* fir, size_t fir_floats, doub
  * results, first_bad_bits (device, 4 bytes) the smallest differing input's bits (0xFFFFFFFF: none). */
 int zns_selftest_div_sqrt_half(unsigned long long* mismatches, unsigned* first_bad_bits, void* stream);
 
-/* Tuning aid: with ZNS_XQT_STAMPS set in the environment the fused generate_XQT kernel records s_memtime stamps of its
+/* Tuning aid: with ZNS_TUNE_XQT_STAMPS set (zns_test_set_tuning) the fused generate_XQT kernel records s_memtime stamps of its
  * workgroup 0 (steps 64..95 x 12 waves x 8 stamps); this copies the last launch's stamps to `host_out` (n <= 3072 values)
  * after synchronising the device.  Returns ZNS_ERR_ARG when no stamped launch has run. */
 int zns_xqt_debug_stamps(unsigned long long* host_out, size_t n);

@@ -29,8 +29,26 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.TEST_SIGNATURES.keys()) == tsyms and not set(tsyms) & set(syms)
     for s in tsyms:
         assert hasattr(L, s), f"libzns_hip.so does not export {s}"
-    for word in ("zns_set_impl", "zns_probe", "selftest", "host_bank", "debug"):
+    for word in ("zns_set_impl", "zns_probe", "selftest", "host_bank", "debug", "tuning", "ZNS_TUNE"):
         assert word not in open(os.path.join(ROOT, "include", "zns.h")).read()
+
+
+def test_library_reads_no_environment_variable():
+    """The product library takes its tuning knobs through include/zns_test.h only: no getenv, no ZNS_* variable name in the
+    binary (flag names inside error messages -- ZNS_XQT_SEPARATE ... -- are C macros of zns.h, not variables)."""
+    import subprocess
+    from zeronotesamba_amd import _lib
+    nm = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True)
+    assert nm.returncode == 0
+    assert not re.search(r"\b(secure_)?getenv\b", nm.stdout), "libzns_hip.so imports getenv"
+    for f in os.listdir(os.path.join(ROOT, "zeronotesamba_amd", "csrc")):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(ROOT, "zeronotesamba_amd", "csrc", f)).read(), f
+    L = _lib.lib()
+    assert L.zns_test_get_tuning(_lib.ZNS_TUNE_KSPLIT) == -1 and L.zns_test_get_tuning(_lib.ZNS_TUNE_XQT_DBG) == 0
+    assert L.zns_test_set_tuning(_lib.ZNS_TUNE_COUNT, 1) != 0 and L.zns_test_set_tuning(-1, 1) != 0
+    assert L.zns_test_set_tuning(_lib.ZNS_TUNE_IPW, 3) == 0 and L.zns_test_get_tuning(_lib.ZNS_TUNE_IPW) == 3
+    assert L.zns_test_set_tuning(_lib.ZNS_TUNE_IPW, 0) == 0
 
 
 def test_host_only_entry_points():

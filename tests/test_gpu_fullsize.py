@@ -177,8 +177,11 @@ def test_clmr_style_shared_branch_module_api():
     assert ((g_both - (g_a + g_p)).norm() / g_both.norm()).item() < 1e-5
 
 
-def test_full_size_step_against_the_cpu_oracle():
-    """BASELINE config 3 at its full size (B=16 pairs, T=512), dropout off: the fused trainer's loss, cosine statistics,
+@pytest.mark.parametrize("T", [512, 313, 626])
+def test_full_size_step_against_the_cpu_oracle(T):
+    """BASELINE config 3 at its full size (B=16 pairs; T=512 the benchmarked tile, T=313 the crop the reference trains
+    on -- pretext.py:285 -- and T=626 a whole bank row; at 313 and 626 cv7 / cv8 take the K-split kernels), dropout
+    off: the fused trainer's loss, cosine statistics,
     embeddings and every parameter gradient against the CPU oracle (stock torch ops, numerically the reference:
     tests/test_oracle.py).  One oracle step takes ~12 s on the box's 16 host cores; two are run:
       (1) mask replay -- the oracle takes the device's max-pool / ReLU decisions (tests/replay_util.py): every
@@ -189,7 +192,7 @@ def test_full_size_step_against_the_cpu_oracle():
     from replay_util import device_decisions, flip_summary, grad_err, rel_l2, total_flips
     from zeronotesamba_amd import _ops
     from zeronotesamba_amd.pretext import PretextTrainer
-    B, T, tau = 16, 512, 0.25
+    B, tau = 16, 0.25
     torch.set_num_threads(host_threads())
     model = build(2)
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
@@ -207,7 +210,7 @@ def test_full_size_step_against_the_cpu_oracle():
     assert abs(out3[0] - loss) < 2e-5 and abs(out3[1] - cpos) < 2e-5 and abs(out3[2] - cneg) < 2e-5
     assert (emb.cpu() - torch.cat([ra, rp])).abs().max().item() < 1e-4
     ref = op.grads()
-    print("full-size step vs CPU oracle with the device's decisions replayed: loss %.6f/%.6f" % (out3[0], loss))
+    print("full-size step T=%d vs CPU oracle with the device's decisions replayed: loss %.6f/%.6f" % (T, out3[0], loss))
     print("  decisions overridden:", flip_summary(flips), "(total %d)" % total_flips(flips))
     worst = 0.0
     for name, p in model.named_parameters():

@@ -339,15 +339,16 @@ def test_compute_entry_points_refuse_degenerate_extents():
 
 
 @pytest.mark.parametrize("li,T", [(6, 313), (7, 313), (6, 40), (7, 200), (6, 1876)])
-def test_k_split_cv7_cv8_equal_the_unsplit_kernels(monkeypatch, li, T):
+def test_k_split_cv7_cv8_equal_the_unsplit_kernels(li, T):
     """cv7 / cv8 forward and backward-data with the input-channel loop split over workgroups (zns_conv_mfma.hip, F7k / F8k /
-    D7k + conv_split_finish_kernel) against the unsplit kernels (ZNS_KSPLIT=0): same products, eight partial chains instead
+    D7k + conv_split_finish_kernel) against the unsplit kernels (zns_test_set_tuning(ZNS_TUNE_KSPLIT, 0)): same products, eight partial chains instead
     of one -- 1e-5 of the result's scale; dropout decisions are index hashes and the backward's zeros (ReLU / dropout mask of
     the input, arg-max unpooling: cv7's backward-data feeds cv6's 8-row pool) sit in the same places.  2 / 4 / 8 ways likewise."""
-    from zeronotesamba_amd import _ops
+    from zeronotesamba_amd import _lib, _ops
     DEV = "cuda:0"
     name, cin, cout, kh, kw, pool = _ops.LAYERS[li]
     nbr, B = 2, 2
+    L = _lib.lib()
     g = torch.Generator().manual_seed(100 * li + T)
     x = torch.randn((nbr * B, cin, 1, T), generator=g).clamp_(min=0).to(DEV)
     w = [(torch.randn((cout, cin, kh, kw), generator=g) / (cin * kw) ** 0.5).to(DEV) for _ in range(nbr)]
@@ -356,15 +357,15 @@ def test_k_split_cv7_cv8_equal_the_unsplit_kernels(monkeypatch, li, T):
     pp = 8 if li == 6 else 1
     am = torch.randint(0, pp, (nbr * B, cin, 1, T), generator=g, dtype=torch.uint8).to(DEV) if pp > 1 else None
     outs = {}
-    for mode in ("0", "2", "4", "8", None):
-        if mode is None:
-            monkeypatch.delenv("ZNS_KSPLIT", raising=False)
-        else:
-            monkeypatch.setenv("ZNS_KSPLIT", mode)
-        ws = _ops.workspace(_ops.conv_workspace_bytes(nbr, B, T), torch.device(DEV), 0)
-        y, _, _ = _ops.conv_fwd(li, nbr, B, T, x, w, b, 0.1, 77, False, ws)
-        dx = _ops.conv_dgrad(li, nbr, B, T, dz, w, x, 1.0 / 0.9, am, pp, ws)
-        outs[mode] = (y.clone(), dx.clone())
+    try:
+        for mode in ("0", "2", "4", "8", None):
+            assert L.zns_test_set_tuning(_lib.ZNS_TUNE_KSPLIT, -1 if mode is None else int(mode)) == 0
+            ws = _ops.workspace(_ops.conv_workspace_bytes(nbr, B, T), torch.device(DEV), 0)
+            y, _, _ = _ops.conv_fwd(li, nbr, B, T, x, w, b, 0.1, 77, False, ws)
+            dx = _ops.conv_dgrad(li, nbr, B, T, dz, w, x, 1.0 / 0.9, am, pp, ws)
+            outs[mode] = (y.clone(), dx.clone())
+    finally:
+        L.zns_test_set_tuning(_lib.ZNS_TUNE_KSPLIT, -1)
     y0, d0 = outs["0"]
     assert torch.equal(outs[None][0], outs["8"][0]) and torch.equal(outs[None][1], outs["8"][1])   # T-only rule: all eight
     for mode in ("2", "4", "8"):

@@ -48,6 +48,9 @@ def cpu_oracle(n_clips=2):
 if __name__ == "__main__":
     if "--stages" in sys.argv:       # e.g. 7 = 3 | ZNS_XQT_SEPARATE, 11 = 3 | ZNS_XQT_FUSED, 19 = 3 | ZNS_XQT_EXACT
         STAGES = int(sys.argv[sys.argv.index("--stages") + 1])
+    if "--plan" in sys.argv:         # decimation chains as digits, e.g. 223 (include/zns_test.h: ZNS_TUNE_XQT_PLAN)
+        from zeronotesamba_amd import _lib as _l
+        _l.check(_l.lib().zns_test_set_tuning(_l.ZNS_TUNE_XQT_PLAN, int(sys.argv[sys.argv.index("--plan") + 1])), "plan")
     sizes = ((32, 50), (64, 30), (128, 20), (256, 10), (512, 10), (4096, 3))
     if "--only" not in sys.argv: sizes = (sizes[0], sizes[4], sizes[5])
     if "--only" in sys.argv:

@@ -1,16 +1,16 @@
 #!/usr/bin/env python3
-"""Where a step of the fused generate_XQT kernel goes: s_memtime stamps of workgroup 0 (ZNS_XQT_STAMPS=1), steps 64..95.
+"""Where a step of the fused generate_XQT kernel goes: s_memtime stamps of workgroup 0 (ZNS_TUNE_XQT_STAMPS), steps 64..95.
 Stamps per wave: 0 step start, 1 (pyramid: inputs requested / filter: tiles staged), 2 (pyramid: outputs written / filter:
 big octave multiplied and stored), 3 arrival at the barrier, 4 release.  Prints per-wave medians in cycles.
-Run on the GPU box: ZNS_XQT_STAMPS=1 python tools/xqt_stamps.py [n_clips]"""
+Run on the GPU box: python tools/xqt_stamps.py [n_clips]"""
 import ctypes as C, os, sys
-os.environ.setdefault("ZNS_XQT_STAMPS", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from zeronotesamba_amd import _lib
 from zeronotesamba_amd.processing.input_rep import generate_XQT_batch
 
+_lib.lib().zns_test_set_tuning(_lib.ZNS_TUNE_XQT_STAMPS, 1)
 n_clips = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 g = torch.Generator().manual_seed(1)
 y = (0.1 * torch.randn(min(n_clips, 512), 160000, generator=g)).cuda()

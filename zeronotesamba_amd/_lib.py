@@ -58,6 +58,8 @@ SIGNATURES = {
 # include/zns_test.h: test / bench only (kernel-family switch, measurement probe, self-tests, host tables)
 TEST_SIGNATURES = {
     "zns_set_impl": (C.c_int, [C.c_int]),
+    "zns_test_set_tuning": (C.c_int, [C.c_int, C.c_int]),
+    "zns_test_get_tuning": (C.c_int, [C.c_int]),
     "zns_probe_arm": (C.c_int, [C.c_int] * 4 + [c_pp, c_pp, C.c_int]),
     "zns_probe_count": (C.c_int, []),
     "zns_xqt_host_bank": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_size_t,
@@ -71,6 +73,9 @@ ZNS_REDUCE_MAX, ZNS_REDUCE_MEAN = 0, 1
 ZNS_MODE_VQT, ZNS_MODE_CQT = 0, 1
 ZNS_XQT_SEPARATE, ZNS_XQT_FUSED, ZNS_XQT_EXACT = 4, 8, 16
 ZNS_ERR_MODE = -3
+# include/zns_test.h: keys of zns_test_set_tuning (tests / tools only; the library reads no environment variable)
+(ZNS_TUNE_KSPLIT, ZNS_TUNE_IPW, ZNS_TUNE_XQT_PLAN, ZNS_TUNE_XQT_LDS_PAD, ZNS_TUNE_XQT_TPW, ZNS_TUNE_XQT_CHUNKS,
+ ZNS_TUNE_XQT_DBG, ZNS_TUNE_XQT_STAMPS, ZNS_TUNE_WIN128, ZNS_TUNE_COUNT) = range(10)
 
 
 def lib() -> C.CDLL:

@@ -14,6 +14,11 @@ static thread_local char g_err[512] = "";
 static std::atomic<int> g_impl{ZNS_IMPL_AUTO};   // process-wide ON PURPOSE: autograd runs backward() on its own thread, which
                                                   // must launch the family the test selected on the Python thread
 Probe g_probe;
+Tuning g_tuning = [] {
+    Tuning t{};
+    t.v[ZNS_TUNE_KSPLIT] = -1;   // automatic
+    return t;
+}();
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -44,6 +49,16 @@ int zns_version(void) { return 104; }   // 101: dzspec_out / dzspec, 102: stem m
 int zns_set_impl(int impl) {
     return g_impl.exchange(impl);
 }
+
+int zns_test_set_tuning(int key, int value) {
+    if (key < 0 || key >= ZNS_TUNE_COUNT) {
+        zns::set_error("zns_test_set_tuning: unknown key %d", key);
+        return ZNS_ERR_ARG;
+    }
+    zns::g_tuning.v[key] = value;
+    return ZNS_OK;
+}
+int zns_test_get_tuning(int key) { return key >= 0 && key < ZNS_TUNE_COUNT ? zns::g_tuning.v[key] : 0; }
 
 static std::mutex g_probe_mu;
 int zns_probe_arm(int kind, int cin, int cout, int kh, void* const* ev_start, void* const* ev_stop, int n) {

@@ -78,6 +78,14 @@ struct MPtr2 {
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Tuning / diagnostic knobs of tests and tools: set ONLY through zns_test_set_tuning (include/zns_test.h), never read from
+// the environment -- a stray variable in a training job must not change sums or skip stores.  Defaults = the product path.
+struct Tuning {
+    int v[ZNS_TUNE_COUNT];
+};
+extern Tuning g_tuning;
+static inline int tuning(int key) { return g_tuning.v[key]; }
+
 // Function attributes (MaxDynamicSharedMemorySize) and device allocations are PER DEVICE: "done once" state is keyed
 // by the calling thread's current device, so a process that drives several GPUs (e.g. the reference's branch-per-device
 // placement, pretext.py:199-200) configures each of them.

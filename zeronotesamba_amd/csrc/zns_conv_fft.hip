@@ -870,10 +870,10 @@ static int run_fconv(const ConvArgs& a, const FftGeom& g, Ptr2 w, int transposed
     A.dil = g.NB;
     A.ncb = ceil_div(g.P, C::WB);
     // two-kind layout: consecutive (sample, slot) items per workgroup (one block per item, 16-byte aligned plain stores): the
-    // largest of 4 / 3 / 2 that divides the items and still leaves a workgroup for every CU (ZNS_IPW overrides: tuning)
+    // largest of 4 / 3 / 2 that divides the items and still leaves a workgroup for every CU (ZNS_TUNE_IPW overrides: tuning)
     A.ipw = 1;
     if constexpr (C::HET > 0 && C::EPI_SEP) {
-        static const int ipw_env = [] { const char* e = getenv("ZNS_IPW"); return e ? atoi(e) : 0; }();
+        const int ipw_env = tuning(ZNS_TUNE_IPW);
         if (A.ncb == 1 && C::COUT == C::COB && (g.P & 3) == 0 && (reinterpret_cast<uintptr_t>(s_out) & 15) == 0) {
             if (ipw_env > 0) {
                 A.ipw = ipw_env;

@@ -99,6 +99,9 @@ static size_t packed_bytes(const ConvArgs& a) {
     return (size_t)a.nbr * a.cout * a.cin * a.kh * a.kw * sizeof(float);
 }
 
+template <class C>
+static int ksplit_ways(const ConvArgs& a);
+
 size_t mfma_workspace_bytes(const ConvArgs& a) {
     size_t slab = 0;
     switch (layer_of(a)) {
@@ -113,7 +116,8 @@ size_t mfma_workspace_bytes(const ConvArgs& a) {
     }
     const size_t pk = (packed_bytes(a) + 255) & ~(size_t)255;
     size_t need = pk > slab ? pk : slab;
-    if (layer_of(a) >= 7) {       // the K-split forward / backward-data: packed operand + partial sums (COUT = max(cin, cout))
+    // the K-split forward / backward-data: packed operand + partial sums (COUT = max(cin, cout)), only where the launch splits
+    if (layer_of(a) >= 7 && (ksplit_ways<F7k>(a) > 1 || ksplit_ways<D7k>(a) > 1)) {
         const size_t part = (size_t)KSPLIT_PARTS * a.nbr * a.B * (a.cin > a.cout ? a.cin : a.cout) * a.T * sizeof(float);
         if (pk + part > need) need = pk + part;
     }
@@ -224,10 +228,7 @@ __global__ void __launch_bounds__(256) conv_split_finish_kernel(const float* __r
     }
 }
 
-static int ksplit_mode() {
-    const char* e = getenv("ZNS_KSPLIT");          // read per call: a test compares the two paths in one process
-    return e ? atoi(e) : -1;                        // -1: automatic; 0: off; 2 / 4 / 8: forced split
-}
+static int ksplit_mode() { return tuning(ZNS_TUNE_KSPLIT); }   // -1: automatic; 0: off; 2 / 4 / 8: forced split (tests)
 // How many ways the K loop of a cv7 / cv8 launch is split (1 = the unsplit kernels): all eight, or not at all -- and the
 // choice follows T alone, never the batch: the summation order of a clip's activations must not depend on the batch it is
 // in (tests/test_gpu_fullsize.py: a batch of 80 equals its chunks of 16 bit for bit).  Rows whose 64-column tiles come in
@@ -238,7 +239,7 @@ static int ksplit_mode() {
 // The split sums are also the more accurate ones (eight chains of an eighth of the terms: 3.5e-7 against 9.6e-7 rms of a
 // float64 convolution) -- which moves them AWAY from the float32 CPU oracle, whose own chain errs like the unsplit kernel's:
 // at T = 512 the full-size oracle test's worst gradient read 1.01e-4 of its norm with the split against 6.2e-5 without.
-// ZNS_KSPLIT=0 / 2 / 4 / 8 overrides (tuning).
+// zns_test_set_tuning(ZNS_TUNE_KSPLIT, 0 / 2 / 4 / 8) overrides (tests, tuning).
 template <class C>
 static int ksplit_ways(const ConvArgs& a) {
     if (a.H != 1) return 1;
@@ -256,7 +257,10 @@ static size_t ksplit_slab_bytes(const ConvArgs& a) {
 template <class C, class CP, int MODE>
 static int launch_split(const ConvArgs& a, const float* x, Ptr2 w, int transposed, const float* wpk, SplitFin F, int ks,
                         void* ws, size_t ws_bytes, hipStream_t st) {
-    static_assert(C::EPI == 1 && C::KH == 1 && C::H == 1 && CP::CIN == C::CIN * KSPLIT_PARTS && same_pack_layout<C, C>(), "split cfg");
+    static_assert(C::EPI == 1 && C::KH == 1 && C::H == 1 && CP::CIN == C::CIN * KSPLIT_PARTS, "split cfg");
+    // the part kernel streams the operand packed for its full-CIN twin: everything the packing depends on must agree
+    static_assert(CP::COB == C::COB && CP::CK == C::CK && CP::MT == C::MT && CP::WM == C::WM && CP::COUT == C::COUT &&
+                  CP::KW == C::KW && CP::KH == C::KH, "split cfg: part and packing twin differ in the packed layout");
     const size_t pk = (packed_bytes(a) + 255) & ~(size_t)255;
     const size_t need = pk + ksplit_slab_bytes<C>(a);
     if (ws_bytes < need) { set_error("conv (K-split): workspace %zu < %zu", ws_bytes, need); return ZNS_ERR_WORKSPACE; }

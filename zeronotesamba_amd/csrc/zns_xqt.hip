@@ -703,7 +703,7 @@ int zns_xqt_host_bank(int mode, int* n_fft8, float* fir, size_t fir_floats, doub
 
 int zns_xqt_debug_stamps(unsigned long long* host_out, size_t n) {
     unsigned long long* d = xqt_stream_stamps();
-    ZNS_CHECK_ARG(d != nullptr && host_out != nullptr && n <= 32 * 12 * 8, "xqt_debug_stamps: no stamped launch (set ZNS_XQT_STAMPS)");
+    ZNS_CHECK_ARG(d != nullptr && host_out != nullptr && n <= 32 * 12 * 8, "xqt_debug_stamps: no stamped launch (zns_test_set_tuning: XQT_STAMPS)");
     ZNS_HIP(hipDeviceSynchronize());
     ZNS_HIP(hipMemcpy(host_out, d, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return ZNS_OK;
@@ -786,7 +786,7 @@ int zns_xqt_stages_f32(const float* wav, int n_clips, int n_samples, int sample_
     }
     // decimation pyramid: levels 1..7, grouped into chains (one launch each).  Default plan: the two big levels on
     // their own (no recomputed halo where 3/4 of the taps are), then chains of two and three (the small levels' launches
-    // are latency-bound: 6.5 us each for a 32-clip batch).  ZNS_XQT_PLAN="n1,n2,.." overrides the grouping (tuning aid).
+    // are latency-bound: 6.5 us each for a 32-clip batch).  ZNS_TUNE_XQT_PLAN overrides the grouping (tuning aid, include/zns_test.h).
     if (stages & 1) {
         // big batches: one launch per level (the fused tail recomputes halos and runs few blocks); small ones: chains of
         // 2 + 2 + 3 levels.  tools/exp_xqt_plan_sweep.py, 32 clips, whole transform with the float32 pyramid: 49.6 us against
@@ -795,18 +795,17 @@ int zns_xqt_stages_f32(const float* wav, int n_clips, int n_samples, int sample_
         int plan[XQ_OCT] = {2, 2, 3, 1, 1, 1, 1}, nplan = 3;
         if (exact) { plan[0] = 1; plan[1] = 1; plan[2] = 2; plan[3] = 3; nplan = 4; }
         if (n_clips >= 256) { nplan = 7; for (int i = 0; i < 7; ++i) plan[i] = 1; }
-        if (const char* e = getenv("ZNS_XQT_PLAN")) {
+        if (const int tp = tuning(ZNS_TUNE_XQT_PLAN)) {      // decimal digits, first chain first: 1123 = {1, 1, 2, 3}
+            int digits[XQ_OCT], nd = 0, tot = 0;
+            for (int q = tp; q > 0 && nd < XQ_OCT; q /= 10) digits[nd++] = q % 10;
             nplan = 0;
-            int tot = 0;
-            for (const char* q = e; *q && nplan < XQ_OCT;) {
-                const int v = atoi(q);
-                ZNS_CHECK_ARG(v >= 1 && v <= DC_MAXLEV, "ZNS_XQT_PLAN: chain of %d levels (1..%d)", v, DC_MAXLEV);
+            for (int i = nd - 1; i >= 0; --i) {
+                const int v = digits[i];
+                ZNS_CHECK_ARG(v >= 1 && v <= DC_MAXLEV, "ZNS_TUNE_XQT_PLAN: chain of %d levels (1..%d)", v, DC_MAXLEV);
                 plan[nplan++] = v;
                 tot += v;
-                while (*q && *q != ',') ++q;
-                if (*q == ',') ++q;
             }
-            ZNS_CHECK_ARG(tot == XQ_OCT - 1, "ZNS_XQT_PLAN must cover the %d decimation levels", XQ_OCT - 1);
+            ZNS_CHECK_ARG(tot == XQ_OCT - 1, "ZNS_TUNE_XQT_PLAN must cover the %d decimation levels", XQ_OCT - 1);
         }
         static const int gl_max[DC_MAXLEV + 1] = {0, 256, 119, 50, 16};   // G[0] = (GL + 18) 2^(nlev-1) - 18 <= DC_S - 9
         int a = 0;   // source level of the next chain
@@ -830,10 +829,13 @@ int zns_xqt_stages_f32(const float* wav, int n_clips, int n_samples, int sample_
             const dim3 grid((unsigned)((size_t)n_clips * P.blocks_per_clip));
             if (exact) {
                 size_t lds = (size_t)(nlev > 1 ? 2 : 1) * DC_WIN * sizeof(double);
-                if (const char* e = getenv("ZNS_XQT_LDS_PAD")) {      // tuning aid: cap the chain kernel's occupancy through its LDS size
-                    lds = std::max(lds, (size_t)atoi(e) * 1024);
-                    static bool set = false;
-                    if (!set) { ZNS_HIP(hipFuncSetAttribute((const void*)decimate_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); set = true; }
+                if (const int pad_kib = tuning(ZNS_TUNE_XQT_LDS_PAD)) {      // tuning aid: cap the chain kernel's occupancy through its LDS size
+                    lds = std::max(lds, (size_t)pad_kib * 1024);
+                    static bool set[ZNS_MAX_DEVICES] = {};
+                    if (!set[current_device_slot()]) {
+                        ZNS_HIP(hipFuncSetAttribute((const void*)decimate_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                        set[current_device_slot()] = true;
+                    }
                 }
                 hipLaunchKernelGGL(decimate_chain_kernel, grid, dim3(256), lds, st, P, b->taps);
             } else {
@@ -859,7 +861,7 @@ int zns_xqt_stages_f32(const float* wav, int n_clips, int n_samples, int sample_
     // single tiles so that the launch still covers the chip (32 clips: 1280 blocks instead of 256).  Measured, kernel
     // time of the filter bank, tpw = 1 / 5: 32 clips 23 / 29 us, 64 clips 41 / 35 us, 4096 clips 2.22 / 1.69 ms.
     F.tpw = n_clips < 64 ? 1 : std::max(1, std::min(FB_TPW, (F.tiles + 3) / 4));
-    if (const char* e = getenv("ZNS_XQT_TPW")) F.tpw = std::max(1, std::min(FB_TPW, atoi(e)));   // tuning aid
+    if (const int tpw = tuning(ZNS_TUNE_XQT_TPW)) F.tpw = std::max(1, std::min(FB_TPW, tpw));   // tuning aid
     F.blocks_per_clip = (F.tiles + 4 * F.tpw - 1) / (4 * F.tpw);
     F.n_clips = n_clips;
     {

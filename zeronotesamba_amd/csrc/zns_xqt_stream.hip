@@ -570,20 +570,21 @@ int xqt_stream_launch(const Bank* b, const float* wav, int n_clips, int n_sample
     const int tiles = (A.T + 15) / 16;
     int nck = 1;
     if (n_clips < ncu) nck = std::max(1, std::min(tiles / 2, ncu / n_clips));
-    if (const char* e = getenv("ZNS_XQT_CHUNKS")) nck = std::max(1, std::min(tiles, atoi(e)));     // tuning aid
+    if (const int ck = tuning(ZNS_TUNE_XQT_CHUNKS)) nck = std::max(1, std::min(tiles, ck));     // tuning aid
     A.chs = (tiles + nck - 1) / nck;
     A.nck = (tiles + A.chs - 1) / A.chs;
     A.W = A.nck > 1 ? 2 : 0;
     A.K = A.W + A.chs + 2;
     A.nitems = n_clips * A.nck;
     A.G = std::min(A.nitems, ncu);
-    if (const char* e = getenv("ZNS_XQT_DBG")) A.dbg = atoi(e);
-    static unsigned long long* g_stamps = nullptr;
-    if (getenv("ZNS_XQT_STAMPS")) {      // tuning aid: cycle stamps of workgroup 0, dumped by zns_xqt_debug_stamps
-        if (!g_stamps) ZNS_HIP(hipMalloc(&g_stamps, 32 * 12 * 8 * sizeof(unsigned long long)));
-        ZNS_HIP(hipMemsetAsync(g_stamps, 0, 32 * 12 * 8 * sizeof(unsigned long long), st));
-        A.stamps = g_stamps;
-        g_last_stamps = g_stamps;
+    A.dbg = tuning(ZNS_TUNE_XQT_DBG);      // phase-skipping bits: timing diagnosis only (include/zns_test.h)
+    static unsigned long long* g_stamps[ZNS_MAX_DEVICES] = {};
+    if (tuning(ZNS_TUNE_XQT_STAMPS)) {      // tuning aid: cycle stamps of workgroup 0, dumped by zns_xqt_debug_stamps
+        unsigned long long*& sb = g_stamps[current_device_slot()];
+        if (!sb) ZNS_HIP(hipMalloc(&sb, 32 * 12 * 8 * sizeof(unsigned long long)));
+        ZNS_HIP(hipMemsetAsync(sb, 0, 32 * 12 * 8 * sizeof(unsigned long long), st));
+        A.stamps = sb;
+        g_last_stamps = sb;
     }
     const size_t lds = (size_t)LDS_FLOATS * sizeof(float);
     static bool lds_set[ZNS_MAX_DEVICES] = {};
