@@ -59,3 +59,42 @@ def test_feature_rms_against_a_direct_numpy_framing():
     want = np.array([np.sqrt(np.mean(np.abs(ypad[t * 512:t * 512 + 2048].astype(np.float64)) ** 2)) for t in range(n_frames)])
     assert got.shape == (1, n_frames)
     np.testing.assert_allclose(got[0], want, rtol=2e-6)
+
+
+@pytest.mark.parametrize("n", [4097, 1000, 999, 131, 70, 64, 5, 1])
+def test_decimation_against_scipys_polyphase_resamplers(n):
+    """The restated 2:1 decimation (resampy.resample(x, 2, 1, 'kaiser_fast') as librosa.resample calls it) against two
+    independent implementations of "filter with these 63 taps, keep every second sample": scipy.signal.upfirdn and
+    scipy.signal.resample_poly.  This pins what a restatement gets wrong first -- the PHASE (output t is centred on input
+    2t), the EDGES (zeros outside the signal, no reflection) and the LENGTH rules (resampy computes int(n / 2) outputs,
+    librosa pads to ceil(n / 2) with zeros) -- to third-party code that is in this image.  The taps themselves are pinned
+    by test_kaiser_fast_window_from_scipys_kaiser; the float32 per-tap rounding is resampy's own and stays unpinned."""
+    scipy_signal = pytest.importorskip("scipy.signal")
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n).astype(np.float32)
+    got = vqt_ref.resample2(x, accumulate="float64")
+    n_out, n_fix = n // 2, (n + 1) // 2
+    assert got.shape == (n_fix,) and got.dtype == np.float32
+    left, right = vqt_ref.decimate2_taps()
+    h = np.concatenate([right[::-1], left])                 # by input offset +31 .. +1, 0, -1 .. -31: h[k] multiplies x[2t + 31 - k]
+    np.testing.assert_array_equal(h, h[::-1])                # a symmetric, odd-length (zero-phase) filter
+    scale = np.float32(np.sqrt(0.5))
+    x64 = x.astype(np.float64)
+    # upfirdn: full convolution sampled at even indices; a leading zero tap puts output t + 16 on input 2t
+    full = scipy_signal.upfirdn(np.concatenate([[0.0], h]), x64, up=1, down=2)
+    want = np.zeros(n_fix, dtype=np.float32)
+    want[:n_out] = full[16:16 + n_out].astype(np.float32)
+    want /= scale
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-7 * max(1.0, float(np.abs(want).max())))
+    # resample_poly centres an odd-length window itself and zero-pads the edges (padtype="constant")
+    poly = scipy_signal.resample_poly(x64, 1, 2, window=h, padtype="constant")
+    assert poly.shape == (n_fix,)
+    want2 = np.zeros(n_fix, dtype=np.float32)
+    want2[:n_out] = poly[:n_out].astype(np.float32)          # for odd n scipy computes one more real output; librosa pads a zero
+    want2 /= scale
+    np.testing.assert_allclose(got, want2, rtol=0, atol=2e-7 * max(1.0, float(np.abs(want2).max())))
+    if n % 2:
+        assert got[-1] == 0.0
+    # and the shipped arithmetics are roundings of the same sums
+    for acc in ("resampy", "fma32"):
+        np.testing.assert_allclose(vqt_ref.resample2(x, accumulate=acc), got, rtol=0, atol=4e-6 * max(1.0, float(np.abs(got).max())))
