@@ -373,3 +373,57 @@ def test_k_split_cv7_cv8_equal_the_unsplit_kernels(li, T):
         assert torch.equal(d == 0, d0 == 0)          # mask and arg-max decide; (a forward sum next to 0 may change sides)
         assert (y - y0).abs().max().item() <= 1e-5 * y0.abs().max().item()
         assert (d - d0).abs().max().item() <= 1e-5 * d0.abs().max().item()
+
+
+@pytest.mark.parametrize("li", [2, 3])
+@pytest.mark.parametrize("T,nbr,B", [(512, 2, 2), (313, 2, 1), (626, 1, 1), (1876, 1, 1), (32, 1, 2), (45, 2, 1), (115, 1, 1),
+                                     (229, 1, 3), (343, 2, 1), (700, 1, 1)])
+def test_window_128_equals_window_64(li, T, nbr, B):
+    """cv3 / cv4 on 128-point overlap-save windows (zns_conv_fft.hip: use_win128, FF3w / FF4w / FD3w tiles, 192 slots)
+    against the same layer on 64-point windows: forward with pooling / dropout / arg-max, backward-data with mask and
+    unpool, backward-weights and bias gradient, with the spectra handed from call to call as the trainer does -- 2e-5 of the
+    result's scale (two summation orders of the same fp32 products).  Lengths: the benchmarked rows, one window (32, 45),
+    exactly V + 1 (115: a second window for one column), every NB from 1 to 6 and rows cut into 2 segments (700, 1876)."""
+    _lib, _ops = _mods()
+    L = _lib.lib()
+    name, cin, cout, kh, kw, pool = _ops.LAYERS[li]
+    H = _ops.H_IN[li]
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(1000 * li + T)
+    x = torch.randn((nbr * B, cin, H, T), generator=g).clamp_(min=0).to(dev)
+    w = [(torch.randn((cout, cin, kh, kw), generator=g) / (cin * kh * kw) ** 0.5).to(dev) for _ in range(nbr)]
+    b = [(torch.randn((cout,), generator=g) * 0.1).to(dev) for _ in range(nbr)]
+    dz = torch.randn((nbr * B, cout, H, T), generator=g).to(dev)
+    pp = _ops.LAYERS[li - 1][5]
+    am_prev = torch.randint(0, pp, (nbr * B, cin, H, T), generator=g, dtype=torch.uint8).to(dev) if pp > 1 else None
+    outs = {}
+    try:
+        for mode in (-1, 1):
+            assert L.zns_test_set_tuning(_lib.ZNS_TUNE_WIN128, mode) == 0
+            ws = _ops.workspace(_ops.conv_workspace_bytes(nbr, B, T), dev, 0)
+            y, am, spec = _ops.conv_fwd(li, nbr, B, T, x, w, b, 0.1, 77, True, ws)
+            dw = [torch.zeros_like(t) for t in w]
+            db = [torch.zeros_like(t) for t in b]
+            dzs = _ops.dz_spectrum(li, nbr, B, T, dev)
+            _ops.conv_wgrad(li, nbr, B, T, dz, x, dw, db, False, ws, xspec=spec, dzspec_out=dzs)
+            dx = _ops.conv_dgrad(li, nbr, B, T, dz, w, x, 1.0 / 0.9, am_prev, pp, ws, dzspec=dzs)
+            dx2 = _ops.conv_dgrad(li, nbr, B, T, dz, w, x, 1.0 / 0.9, am_prev, pp, ws)
+            torch.cuda.synchronize()
+            assert torch.equal(dx, dx2)                     # handed-over dZ spectrum == transformed by the call itself
+            outs[mode] = (y.clone(), am.clone() if am is not None else None, dx.clone(), [t.clone() for t in dw], [t.clone() for t in db])
+    finally:
+        L.zns_test_set_tuning(_lib.ZNS_TUNE_WIN128, 0)
+    a, c = outs[-1], outs[1]
+
+    def near(u, v, what, tol=2e-5):
+        s = v.abs().max().item()
+        e = (u - v).abs().max().item()
+        assert e <= tol * max(s, 1e-30), f"{name} T={T} {what}: {e:.3e} of {s:.3e}"
+    # dropout decisions are index hashes: zeros sit in the same places except where a pre-activation is within rounding of 0
+    near(c[0], a[0], "forward")
+    near(c[2], a[2], "backward-data")
+    assert torch.equal(c[2] == 0, a[2] == 0) or ((c[2] == 0) != (a[2] == 0)).sum().item() < 1e-5 * a[2].numel()
+    for u, v in zip(c[3], a[3]):
+        near(u, v, "backward-weights")
+    for u, v in zip(c[4], a[4]):
+        near(u, v, "bias gradient")

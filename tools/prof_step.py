@@ -12,7 +12,11 @@ ap.add_argument("--frames", type=int, default=313)
 ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--steps", type=int, default=4)
 ap.add_argument("--warmup", type=int, default=2)
+ap.add_argument("--win128", type=int, default=0, help="cv3 / cv4 window length: 0 library rule, 1 force 128-point, -1 force 64-point")
 a = ap.parse_args()
+if a.win128:
+    from zeronotesamba_amd import _lib
+    _lib.check(_lib.lib().zns_test_set_tuning(_lib.ZNS_TUNE_WIN128, a.win128), "tuning")
 dev = torch.device("cuda", 0)
 tr = PretextTrainer(bench.build_model(dev), batch_len=a.batch, seed=1)
 g = torch.Generator().manual_seed(a.batch * 1000 + a.frames)

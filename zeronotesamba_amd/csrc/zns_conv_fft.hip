@@ -28,9 +28,19 @@
 
 namespace zns {
 
-constexpr int FN = 64, FF = 32, FDIL = 12;
-constexpr int FS = 3 * FF;   // weight/spectrum slots per sample: (frequency f, Karatsuba part t) -> 3 f + t
-constexpr int FDILW = 12;   // backward-weights tiles keep two input-channel tiles in LDS: window count per row <= 12
+// Window length FN: 64 samples for cv2 / cv5 / cv6 and for short rows, 128 for cv3 / cv4 where that needs fewer
+// frequency-windows (use_win128).  FF = FN / 2 frequencies, FS = 3 FF weight / spectrum slots per sample: (frequency f,
+// Karatsuba part t) -> 3 f + t.  Every transform kernel is instantiated per window length; the GEMM kernels only see more
+// slots (run-time F) and fewer positions.
+constexpr int FDIL = 12;     // 64-point windows: at most 12 windows per row segment (the row taps are NB positions apart)
+constexpr int FDIL128 = 6;   // 128-point windows: at most 6
+constexpr int FDILW = 12;    // backward-weights tiles keep two input-channel tiles in LDS: window count per row <= 12
+// Transform blocks are 256 threads: one lane per 64-point window, a lane PAIR per 128-point window (zns_fft64.h)
+template <int FN> constexpr int win_per_block() { return FN == 64 ? 256 : 128; }
+// the inverse transform keeps a block's outputs in LDS (V floats per window): 128-thread blocks for 128-point windows
+// (64 windows, 29 KB: five blocks per CU; with 256 threads it was two)
+template <int FN> constexpr int inv_threads() { return FN == 64 ? 256 : 128; }
+template <int FN> constexpr int inv_win_per_block() { return FN == 64 ? 256 : 64; }
 
 // Spectrum planes are addressed as  (per-lane byte offset, wave-uniform plane offset)  through a buffer
 // descriptor: the 96 plane accesses of a window then share ONE address VGPR (the plane offset goes in an SGPR).
@@ -52,46 +62,93 @@ __device__ __forceinline__ void spec_store(__amdgpu_buffer_rsrc_t rs, unsigned v
 // Long rows are cut into NS segments of NB <= 12 windows each; a segment is a separate spectral "sample"
 // n' = n * NS + seg (the row taps of the GEMM stage are NB positions apart, so NB must stay small), NBT = windows
 // of the whole row.
+template <int FN>
 __global__ void __launch_bounds__(256) spec_fwd_kernel(const float* __restrict__ x, float* __restrict__ S, int C,
                                                        int H, int T, int V, int NB, int off, int valid, int chunks,
                                                        float third_sign, int NS, int NBT, float* __restrict__ S2) {
+    constexpr int FF = FN / 2, FS = 3 * FF, WINB = win_per_block<FN>(), K64 = FN / 64, WPW = WINB / 4;   // WPW: windows a wave fetches
     // Windows are staged through LDS so that global reads are coalesced: one wave-instruction fetches ONE window
     // (64 consecutive samples); all 64 fetches of a wave are issued before the first LDS write.  Each lane then
     // reads back its own window (row stride 65 floats: conflict free) and transforms it in registers.
-    __shared__ float win[256 * (FN + 1)];
+    __shared__ float win[WINB * (FN + 1)];
     const int CP = C * H * NB;
     const int chunk = blockIdx.x % chunks;
     const int ns = blockIdx.x / chunks;             // spectral sample = (sample, segment)
     const int n = ns / NS, bseg = (ns - n * NS) * NB;
     const int lane = threadIdx.x & 63;
-    const int wbase = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * 64);
+    const int wbase = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) * WPW);
     const float* xn = x + (size_t)n * C * H * T;
-    float xw[FN];
+    float xw[64];
     {
         // wave-uniform walk: (row R = c*H + h, window bb) of the 64 windows this wave fetches
-        const int qw = chunk * 256 + wbase;
+        const int qw = chunk * WINB + wbase;
         int R = qw / NB, bb = qw - R * NB;
         int left = CP - qw;                           // windows that exist from here on
 #pragma unroll
-        for (int i = 0; i < FN; ++i) {
-            const int col = (bseg + bb) * V - off + lane;
-            xw[i] = (i < left && bseg + bb < NBT && lane < valid && col >= 0 && col < T) ? xn[(size_t)R * T + col] : 0.f;
+        for (int i = 0; i < WPW; ++i) {
+#pragma unroll
+            for (int h = 0; h < K64; ++h) {           // a 128-sample window is two wave-instructions
+                const int smp = lane + 64 * h;
+                const int col = (bseg + bb) * V - off + smp;
+                xw[i * K64 + h] = (i < left && bseg + bb < NBT && smp < valid && col >= 0 && col < T) ? xn[(size_t)R * T + col] : 0.f;
+            }
             if (++bb == NB) { bb = 0; ++R; }
         }
     }
 #pragma unroll
-    for (int i = 0; i < FN; ++i) win[(wbase + i) * (FN + 1) + lane] = xw[i];
+    for (int i = 0; i < WPW; ++i)
+#pragma unroll
+        for (int h = 0; h < K64; ++h) win[(wbase + i) * (FN + 1) + lane + 64 * h] = xw[i * K64 + h];
     __syncthreads();
-    const int q = chunk * 256 + threadIdx.x;
+    const size_t tstride = (size_t)CP;          // between consecutive slots
+    if constexpr (FN == 128) {
+        // a lane pair per window (rfft128_pair): lane par holds samples 4m + 2par + {0, 1} and stores frequencies 32par + j
+        const int w = threadIdx.x >> 1, par = threadIdx.x & 1;
+        const int q = chunk * WINB + w;
+        if (q >= CP) return;                    // (both lanes of a pair leave together)
+        const float* wrow = win + w * (FN + 1) + 2 * par;
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+            xw[2 * m] = wrow[4 * m];
+            xw[2 * m + 1] = wrow[4 * m + 1];
+        }
+        float sr[32], si[32];
+        rfft128_pair(xw, par, sr, si);
+        float* out = S + (size_t)ns * FS * CP + q + (size_t)par * 96 * tstride;
+        const bool dc = par == 0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            out[(3 * j) * tstride] = sr[j];
+            out[(3 * j + 1) * tstride] = si[j];
+            out[(3 * j + 2) * tstride] = (j == 0 && dc) ? 0.f : sr[j] + third_sign * si[j];
+        }
+        if (S2 != nullptr) {
+#pragma unroll
+            for (int m = 0; m < 32; ++m) {
+                const int i0 = 4 * m + 2 * par;
+                xw[2 * m] = (i0 < V) ? wrow[4 * m + off] : 0.f;
+                xw[2 * m + 1] = (i0 + 1 < V) ? wrow[4 * m + 1 + off] : 0.f;
+            }
+            rfft128_pair(xw, par, sr, si);
+            float* out2 = S2 + (size_t)ns * FS * CP + q + (size_t)par * 96 * tstride;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                out2[(3 * j) * tstride] = sr[j];
+                out2[(3 * j + 1) * tstride] = si[j];
+                out2[(3 * j + 2) * tstride] = (j == 0 && dc) ? 0.f : sr[j] - si[j];
+            }
+        }
+        return;
+    }
+    const int q = chunk * WINB + threadIdx.x;
     if (q >= CP) return;
 #pragma unroll
-    for (int m = 0; m < FN; ++m) xw[m] = win[threadIdx.x * (FN + 1) + m];
+    for (int m = 0; m < 64; ++m) xw[m] = win[threadIdx.x * (FN + 1) + m];
     float* out = S + (size_t)ns * FS * CP + q;
-    const size_t tstride = (size_t)CP;          // between consecutive slots
-    float sr[FF], si[FF];
+    float sr[32], si[32];
     rfft64(xw, sr, si);
 #pragma unroll
-    for (int f = 0; f < FF; ++f) {
+    for (int f = 0; f < 32; ++f) {
         out[(3 * f) * tstride] = sr[f];
         out[(3 * f + 1) * tstride] = si[f];
         out[(3 * f + 2) * tstride] = f ? sr[f] + third_sign * si[f] : 0.f;
@@ -100,11 +157,11 @@ __global__ void __launch_bounds__(256) spec_fwd_kernel(const float* __restrict__
         // second spectrum from the same staged samples: the zero-padded V-block of backward-weights is samples
         // [off, off + V) of the overlapped window (both start V apart; off = kw/2), planes (re, im, re - im)
 #pragma unroll
-        for (int m = 0; m < FN; ++m) xw[m] = (m < V) ? win[threadIdx.x * (FN + 1) + m + off] : 0.f;
+        for (int m = 0; m < 64; ++m) xw[m] = (m < V) ? win[threadIdx.x * (FN + 1) + m + off] : 0.f;
         rfft64(xw, sr, si);
         float* out2 = S2 + (size_t)ns * FS * CP + q;
 #pragma unroll
-        for (int f = 0; f < FF; ++f) {
+        for (int f = 0; f < 32; ++f) {
             out2[(3 * f) * tstride] = sr[f];
             out2[(3 * f + 1) * tstride] = si[f];
             out2[(3 * f + 2) * tstride] = f ? sr[f] - si[f] : 0.f;
@@ -134,7 +191,7 @@ struct InvEpi {
     uint32_t mT, mPP;          // FLAT epilogue: divisions by T and by prev_pool
 };
 
-constexpr int IVMAX = FN - 12;     // V <= 52 (kw >= 13)
+template <int FN> constexpr int iv_max() { return FN - 12; }     // V <= FN - 12 (kw >= 13)
 
 __device__ __forceinline__ int fastdiv(int x, int d, uint32_t magic) { return d == 1 ? x : (int)__umulhi((uint32_t)x, magic); }
 static uint32_t div_magic(int d) { return d <= 1 ? 0u : (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d); }
@@ -162,10 +219,11 @@ __device__ __forceinline__ typename VecOf<VW>::type ld_stage(const float* sp) {
     }
 }
 
-template <int MODE, int VW, bool ROW = false, bool FLAT = false>
-__global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__ S, float* __restrict__ out, int C, int H,
+template <int MODE, int VW, bool ROW = false, bool FLAT = false, int FN = 64>
+__global__ void __launch_bounds__(inv_threads<FN>()) spec_inv_kernel(const float* __restrict__ S, float* __restrict__ out, int C, int H,
                                                        int T, int V, int NB, int chunks, int WPB, int NS, InvEpi E) {
-    extern __shared__ __attribute__((aligned(16))) float stage[];   // [256][VS], VS odd: per-lane rows hit distinct banks
+    constexpr int FF = FN / 2, FS = 3 * FF, NTHR = inv_threads<FN>(), IVMAX = iv_max<FN>();
+    extern __shared__ __attribute__((aligned(16))) float stage[];   // [inv_win_per_block<FN>()][VS], VS odd: per-lane rows hit distinct banks
     const int pool = MODE == 1 ? E.pool : 1;
     const int Hq = H / pool;                       // output rows per channel (pooled rows in MODE 1)
     const int CP = C * H * NB;
@@ -178,7 +236,34 @@ __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__
     const unsigned tstride = (unsigned)CP * 4u;    // bytes between consecutive slots
     float* sbase = const_cast<float*>(S) + (size_t)ns * FS * CP;
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(sbase, 0, (int)(tstride * FS), 0x00020000);
-    if ((int)threadIdx.x < nwin) {
+    if constexpr (FN == 128) {
+        // a lane pair per window (irfft128_pair): lane par loads frequencies 32par + j and ends up with samples 4m + 2par + {0, 1}
+        const int w = threadIdx.x >> 1, par = threadIdx.x & 1;
+        if (w < nwin) {
+            const unsigned voff = (unsigned)(q0 + w) * 4u + (unsigned)par * 96u * tstride;
+            float yr[32], yi[32];
+            {
+                const float q1 = spec_load(rs, voff, 0), q2 = spec_load(rs, voff, tstride), q3 = spec_load(rs, voff, 2 * tstride);
+                yr[0] = par ? q1 - q2 : q1;              // lane 0: DC and Nyquist (both real); lane 1: frequency 32
+                yi[0] = par ? q3 - q1 - q2 : q2;
+            }
+#pragma unroll
+            for (int j = 1; j < 32; ++j) {
+                const float q1 = spec_load(rs, voff, (3 * j) * tstride), q2 = spec_load(rs, voff, (3 * j + 1) * tstride),
+                            q3 = spec_load(rs, voff, (3 * j + 2) * tstride);
+                yr[j] = q1 - q2;
+                yi[j] = q3 - q1 - q2;
+            }
+            float xs[64];
+            irfft128_pair(yr, yi, par, xs);
+            float* mine = stage + w * VS + 2 * par;
+#pragma unroll
+            for (int m = 0; m < (IVMAX + 3) / 4; ++m) {
+                if (4 * m + 2 * par < V) mine[4 * m] = xs[2 * m];
+                if (4 * m + 2 * par + 1 < V) mine[4 * m + 1] = xs[2 * m + 1];
+            }
+        }
+    } else if ((int)threadIdx.x < nwin) {
         const unsigned voff = (unsigned)(q0 + threadIdx.x) * 4u;
         float yr[FF], yi[FF];
         yr[0] = spec_load(rs, voff, 0);                  // DC
@@ -191,7 +276,7 @@ __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__
             yi[f] = q3 - q1 - q2;
         }
         float xo[FN];
-        irfft64(yr, yi, xo);
+        irfft<FN>(yr, yi, xo);
         float* mine = stage + threadIdx.x * VS;
 #pragma unroll
         for (int v = 0; v < IVMAX; ++v)
@@ -216,19 +301,19 @@ __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__
         const int shift = (int)(g0 & 3);
         const int nchunk = (count + shift + 3) >> 2;
         constexpr int EV = 2;                          // two chunks per thread and trip: all global loads before the stores
-        for (int e0 = threadIdx.x; e0 < nchunk; e0 += 256 * EV) {
+        for (int e0 = threadIdx.x; e0 < nchunk; e0 += NTHR * EV) {
             float r[EV][4], mk[EV][4];
             int am[EV][4], qq[EV][4], Rqv[EV][4], colv[EV][4];
             bool okv[EV][4];
 #pragma unroll
             for (int u = 0; u < EV; ++u) {
-                const int f0 = 4 * (e0 + u * 256) - shift;
+                const int f0 = 4 * (e0 + u * NTHR) - shift;
                 int rowo = fastdiv(f0 < 0 ? 0 : f0, T, E.mT);
                 int col = (f0 < 0 ? 0 : f0) - rowo * T + (f0 < 0 ? f0 : 0);     // negative only in the block's first chunk
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int f = f0 + k;
-                    okv[u][k] = e0 + u * 256 < nchunk && f >= 0 && f < count;
+                    okv[u][k] = e0 + u * NTHR < nchunk && f >= 0 && f < count;
                     r[u][k] = 0.f; mk[u][k] = 1.f; am[u][k] = 0; qq[u][k] = 0; Rqv[u][k] = 0; colv[u][k] = col;
                     if (okv[u][k]) {
                         const int rin = pp > 1 ? fastdiv(rowo, pp, E.mPP) : rowo;
@@ -266,7 +351,7 @@ __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__
             }
 #pragma unroll
             for (int u = 0; u < EV; ++u) {
-                const int f0 = 4 * (e0 + u * 256) - shift;
+                const int f0 = 4 * (e0 + u * NTHR) - shift;
                 f32x4 val;
                 uint32_t amw = 0u;
                 bool any = false, all = true;
@@ -312,7 +397,7 @@ __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__
         const int V4n = ROW ? T / 4 : V / VW;                       // chunks per row / per window
         const int nout4 = (ROW ? nwin / group : nwin / pool) * V4n;
         constexpr int EV = 2;                      // 2 x 4 outputs per thread and trip, loads before stores
-        for (int e0 = threadIdx.x; e0 < nout4; e0 += 256 * EV) {
+        for (int e0 = threadIdx.x; e0 < nout4; e0 += NTHR * EV) {
             vec_t r[EV], mk[EV];
             uint32_t amw[EV];
             size_t o[EV];
@@ -320,7 +405,7 @@ __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__
             bool ok[EV];
 #pragma unroll
             for (int u = 0; u < EV; ++u) {
-                const int e = e0 + u * 256;
+                const int e = e0 + u * NTHR;
                 const int w = fastdiv(e, V4n, E.mV), v = (e - w * V4n) * VW;   // ROW: w = row in the block, v = column
                 const int lg = ROW ? w : fastdiv(w, NB, E.mNB), b = ROW ? 0 : w - lg * NB;
                 col[u] = ROW ? v : (bseg + b) * V + v;
@@ -394,14 +479,14 @@ __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__
     // four outputs per thread and trip: their global loads (mask, arg-max, bias) are all in flight before the first
     // store, instead of one exposed memory round trip per element
     constexpr int EU = 4;
-    for (int e0 = threadIdx.x; e0 < nout; e0 += 256 * EU) {
+    for (int e0 = threadIdx.x; e0 < nout; e0 += NTHR * EU) {
         float r[EU], mk[EU];
         size_t o[EU];
         int am[EU], Rq[EU], col[EU];
         bool ok[EU];
 #pragma unroll
         for (int u = 0; u < EU; ++u) {
-            const int e = e0 + u * 256;
+            const int e = e0 + u * NTHR;
             const int w = fastdiv(e, V, E.mV), v = e - w * V;          // pooled window inside the block, sample
             const int lg = fastdiv(w, NB, E.mNB), b = w - lg * NB;     // pooling group inside the block, window in its row
             col[u] = (bseg + b) * V + v;
@@ -458,9 +543,11 @@ __global__ void __launch_bounds__(256) spec_inv_kernel(const float* __restrict__
 //   slot 3f+0: Gr   slot 3f+1: Gi   slot 3f+2: Gr + Gi      (f = 0: G(0), G(32), unused)
 // laid out [branch*FS + slot][cob][cc][cp][tap][wm][lane_h][i][m].  One thread owns one (co, ci, tap): it reads the
 // kw time taps once and loops over the 32 frequencies, so every slab is written with coalesced stores.
+template <int FN>
 __global__ void __launch_bounds__(256) pack_freq_weights_kernel(Ptr2 w, float* __restrict__ dst, int cin_c, int cout_c,
                                                                 int kh, int kw, int cob_sz, int ck, int mt, int wm_n,
                                                                 int transposed, long long per_wf, int nbr) {
+    constexpr int FF = FN / 2, FS = 3 * FF;
     const long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= per_wf * nbr) return;
     const int br = (int)(o / per_wf);
@@ -477,7 +564,7 @@ __global__ void __launch_bounds__(256) pack_freq_weights_kernel(Ptr2 w, float* _
     const int cob = (int)q;
     const int co = cob * cob_sz + (wm * mt + m) * 32 + i;
     const int ci = cc * ck + 2 * cp + h;
-    // G[f] = sum_s W[s] e^{+2 pi i f s / 64} = conj(DFT_64(W zero padded)[f]): one register FFT per thread (the first
+    // G[f] = sum_s W[s] e^{+2 pi i f s / FN} = conj(DFT_FN(W zero padded)[f]): one register FFT per thread (the first
     // version summed 32 x kw twiddle products through LDS: 1600 FMAs and 800 LDS reads per thread)
     float x[FN];
     // The kw taps of one (co, ci, row) are ONE contiguous run in the OIHW tensor (4-byte aligned only: kw is odd), and the
@@ -523,10 +610,10 @@ __global__ void __launch_bounds__(256) pack_freq_weights_kernel(Ptr2 w, float* _
         }
     }
     float sr[FF], si[FF];
-    rfft64(x, sr, si);
+    rfft<FN>(x, sr, si);
     float* d = dst + (size_t)br * FS * per_wf + off;
     d[0] = sr[0];                                   // G(0)
-    d[per_wf] = si[0];                              // G(32), real
+    d[per_wf] = si[0];                              // G(FN / 2), real
     d[2 * per_wf] = 0.f;
 #pragma unroll
     for (int f = 1; f < FF; ++f) {
@@ -547,10 +634,12 @@ __global__ void __launch_bounds__(256) pack_freq_weights_kernel(Ptr2 w, float* _
 // The launch also carries the bias gradient: blocks past `rblocks` (one per (branch, output channel)) sum slot 0 "re" of
 // the zero-padded dZ blocks' spectrum (`sz`: each block's sum) over samples and positions -- as its own launch this
 // was 16 us of latency five times per step; here it rides beside the slab reduction.
+template <int FN>
 __global__ void __launch_bounds__(128) wgrad_spec_reduce_kernel(const float* __restrict__ slab, MPtr2 dw, int KS, int cout,
                                                                 int cin, int kh, int kw, int accumulate, int nbr,
                                                                 const float* __restrict__ sz, MPtr2 db, int Bs, int P,
                                                                 int rblocks) {
+    constexpr int FF = FN / 2, FS = 3 * FF;
     extern __shared__ float tile[];                 // [32][kh][kw]
     if ((int)blockIdx.x >= rblocks) {
         const int co = ((int)blockIdx.x - rblocks) % cout, br = ((int)blockIdx.x - rblocks) / cout;
@@ -612,9 +701,9 @@ __global__ void __launch_bounds__(128) wgrad_spec_reduce_kernel(const float* __r
                 __builtin_amdgcn_sched_barrier(0);      // keep the next trip's loads below this one's adds
             }
         }
-        // dW[s] = (1/64) sum_f C[f] e^{+2 pi i f s / 64} (C Hermitian): the inverse real FFT, lags 0 .. kw-1 kept
+        // dW[s] = (1/FN) sum_f C[f] e^{+2 pi i f s / FN} (C Hermitian): the inverse real FFT, lags 0 .. kw-1 kept
         float lag[FN];
-        irfft64(cr, cim, lag);
+        irfft<FN>(cr, cim, lag);
         float* t = tile + ((size_t)ci_l * kh + tap) * kw;
 #pragma unroll
         for (int s = 0; s < 25; ++s)
@@ -660,6 +749,20 @@ using FD3 = ConvCfg<128, 64, 1, 5, 1, 1, 1, 3, 2, 1, 2, 8, 1, 1, FDIL>;
 using FD4 = FF4;
 using FD5 = ConvCfg<256, 128, 1, 3, 1, 1, 1, 1, 4, 1, 3, 16, 1, 1, FDIL>;
 using FD6 = FF6;
+// cv3 / cv4 on 128-point windows (use_win128): P = 32 NB with NB <= 6 windows per row segment -- 160 columns at T = 512,
+// 96 at the reference's T = 313 -- and 192 slots per sample.  Four channel tiles x five column tiles = 20 tiles: four waves of
+// (1 channel tile x 5 column tiles), five tiles on every SIMD, no two-kind layout, no dead twelfth tile; 4-channel stages keep
+// the operands at 45 KB (three workgroups per CU).  `a`: three column tiles per wave for P = 96 / 192 / 288.
+//                   CIN COUT KH KW(taps) H  MT RT CT WM WR WC CK POOL EPI DILMAX
+using FF3w = ConvCfg<64, 128, 1, 5, 1, 1, 1, 5, 4, 1, 1, 8, 1, 1, FDIL128>;
+using FF3wa = ConvCfg<64, 128, 1, 5, 1, 1, 1, 3, 4, 1, 1, 8, 1, 1, FDIL128>;
+using FF4w = ConvCfg<128, 128, 1, 9, 1, 1, 1, 5, 4, 1, 1, 4, 1, 1, FDIL128>;
+using FF4wa = ConvCfg<128, 128, 1, 9, 1, 1, 1, 3, 4, 1, 1, 4, 1, 1, FDIL128>;
+using FD4w = FF4w;
+using FD4wa = FF4wa;
+// cv3 backward-data: two channel tiles x five column tiles = two waves of (1 x 5)
+using FD3w = ConvCfg<128, 64, 1, 5, 1, 1, 1, 5, 2, 1, 1, 8, 1, 1, FDIL128>;
+using FD3wa = ConvCfg<128, 64, 1, 5, 1, 1, 1, 3, 2, 1, 1, 8, 1, 1, FDIL128>;
 //                 CIN COUT KH KW(taps) H  MT NS WMW WQ R DILMAX WCI
 using FW2 = WgCfg<64, 64, 1, 7, 1, 1, 7, 2, 1, 1, FDILW, 2, 32>;
 using FW3 = WgCfg<64, 128, 1, 5, 1, 1, 5, 4, 1, 1, FDILW, 2, 32>;
@@ -668,7 +771,9 @@ using FW5 = WgCfg<128, 256, 1, 3, 1, 2, 3, 2, 1, 1, FDILW, 2, 32>;
 using FW6 = WgCfg<256, 256, 1, 5, 1, 2, 5, 4, 1, 1, FDILW, 2, 32>;
 
 struct FftGeom {
-    int V;      // valid outputs per 64-sample window
+    int FN;     // window length: 64 or 128 samples
+    int FS;     // spectrum / weight slots per sample: 3 * FN / 2
+    int V;      // valid outputs per window
     int NBT;    // windows per image row
     int NS;     // segments a row is cut into (each a separate spectral sample)
     int NB;     // windows per segment (<= FDILW): the row taps of the GEMM stage are NB positions apart
@@ -687,11 +792,26 @@ static int fft_layer_of(const ConvArgs& a) {
     return -1;
 }
 
+// 128-point windows for cv3 / cv4 wherever they need fewer frequency-windows per row than 64-point ones (2 per window
+// against 1: T = 512: 2 x 5 against 11; the reference's T = 313: 2 x 3 against 7; rows under ~100 frames stay on 64).  A
+// function of (layer, T) alone, never of the batch: a clip's sums must not depend on the batch it is in.
+// zns_test_set_tuning(ZNS_TUNE_WIN128, 1 / -1) forces / forbids it (tests compare the two).
+static bool use_win128(const ConvArgs& a) {
+    const int l = fft_layer_of(a);
+    if (l != 3 && l != 4) return false;
+    const int m = tuning(ZNS_TUNE_WIN128);
+    if (m < 0) return false;
+    if (m > 0) return true;
+    return 2 * ceil_div(a.T, 129 - a.kw) < ceil_div(a.T, 65 - a.kw);
+}
+
 static FftGeom geom(const ConvArgs& a) {
     FftGeom g;
-    g.V = FN - a.kw + 1;
+    g.FN = use_win128(a) ? 128 : 64;
+    g.FS = 3 * (g.FN / 2);
+    g.V = g.FN - a.kw + 1;
     g.NBT = ceil_div(a.T, g.V);
-    g.NS = ceil_div(g.NBT, FDILW);
+    g.NS = ceil_div(g.NBT, g.FN == 128 ? FDIL128 : FDILW);
     g.NB = ceil_div(g.NBT, g.NS);
     g.P = a.H * g.NB;
     g.Bs = a.B * g.NS;
@@ -717,7 +837,7 @@ static int fwg_pick_ks(const ConvArgs& a, const FftGeom& g, int* tiles_total, in
     ConvArgs t = a;
     t.B = g.Bs;          // every segment of every sample contributes K tiles
     t.T = g.P;           // K tiles run over the flattened axis
-    t.nbr = a.nbr * FS;  // one accumulation per (branch, frequency, Karatsuba part)
+    t.nbr = a.nbr * g.FS;  // one accumulation per (branch, frequency, Karatsuba part)
     return wg_pick_ks<W>(t, tiles_total, tps);
 }
 
@@ -725,18 +845,18 @@ template <class W>
 static size_t fwg_slab_floats(const ConvArgs& a, const FftGeom& g) {
     int tt, tps;
     const int ks = fwg_pick_ks<W>(a, g, &tt, &tps);
-    return (size_t)a.nbr * FS * ks * W::Q * W::COUT * W::CIN;
+    return (size_t)a.nbr * g.FS * ks * W::Q * W::COUT * W::CIN;
 }
 
 static FftWs fft_ws(const ConvArgs& a) {
     const FftGeom g = geom(a);
     FftWs w{};
     const size_t cmax = (size_t)(a.cin > a.cout ? a.cin : a.cout);
-    const size_t spec = (size_t)g.nb * FS * cmax * g.P * sizeof(float);
+    const size_t spec = (size_t)g.nb * g.FS * cmax * g.P * sizeof(float);
     w.s_in = 0;
     w.s_out = align_up(spec);
     w.wf = w.s_out + align_up(spec);
-    const size_t wfb = (size_t)a.nbr * FS * a.cout * a.cin * a.kh * sizeof(float);
+    const size_t wfb = (size_t)a.nbr * g.FS * a.cout * a.cin * a.kh * sizeof(float);
     size_t slab = 0;
     switch (fft_layer_of(a)) {
         case 2: slab = fwg_slab_floats<FW2>(a, g); break;
@@ -754,28 +874,35 @@ static FftWs fft_ws(const ConvArgs& a) {
 size_t fft_workspace_bytes(const ConvArgs& a) { return fft_supported(a) ? fft_ws(a).total : 0; }
 size_t fft_spectrum_bytes(const ConvArgs& a) {
     const FftGeom g = geom(a);
-    return (size_t)g.nb * FS * a.cin * g.P * sizeof(float);
+    return (size_t)g.nb * g.FS * a.cin * g.P * sizeof(float);
 }
 size_t fft_dz_spectrum_bytes(const ConvArgs& a) {
     const FftGeom g = geom(a);
-    return (size_t)g.nb * FS * a.cout * g.P * sizeof(float);
+    return (size_t)g.nb * g.FS * a.cout * g.P * sizeof(float);
 }
 
 static int run_spec_fwd(const float* x, float* S, int nb, int C, int H, int T, const FftGeom& g, int off, int valid,
                         float third_sign, hipStream_t st, float* S2 = nullptr) {
-    const int chunks = ceil_div(C * g.P, 256);
-    hipLaunchKernelGGL(spec_fwd_kernel, dim3((unsigned)((size_t)nb * chunks)), dim3(256), 0, st, x, S, C, H, T, g.V,
-                       g.NB, off, valid, chunks, third_sign, g.NS, g.NBT, S2);
+    if (g.FN == 128) {
+        const int chunks = ceil_div(C * g.P, win_per_block<128>());
+        hipLaunchKernelGGL(spec_fwd_kernel<128>, dim3((unsigned)((size_t)nb * chunks)), dim3(256), 0, st, x, S,
+                           C, H, T, g.V, g.NB, off, valid, chunks, third_sign, g.NS, g.NBT, S2);
+    } else {
+        const int chunks = ceil_div(C * g.P, 256);
+        hipLaunchKernelGGL(spec_fwd_kernel<64>, dim3((unsigned)((size_t)nb * chunks)), dim3(256), 0, st, x, S, C, H, T, g.V,
+                           g.NB, off, valid, chunks, third_sign, g.NS, g.NBT, S2);
+    }
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
 }
 
-template <int MODE>
-static int run_spec_inv(const float* S, float* out, int nb, int C, int H, int T, const FftGeom& g, InvEpi E,
-                        hipStream_t st) {
+template <int MODE, int FN>
+static int run_spec_inv_n(const float* S, float* out, int nb, int C, int H, int T, const FftGeom& g, InvEpi E,
+                          hipStream_t st) {
+    constexpr int NTHR = inv_threads<FN>(), WINB = inv_win_per_block<FN>();
     const int pool = MODE == 1 ? E.pool : 1;
     const int group = pool * g.NB;
-    const int WPB = (256 / group) * group;
+    const int WPB = (WINB / group) * group;
     const int chunks = ceil_div(C * g.P, WPB);
     auto al = [](const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; };
     int vw = 1;   // samples per thread in the epilogue: the widest vector V, T and every pointer allow
@@ -789,26 +916,32 @@ static int run_spec_inv(const float* S, float* out, int nb, int C, int H, int T,
     E.mV = div_magic(row ? T / 4 : g.V / vw);
     E.mNB = div_magic(g.NB);
     E.mHq = div_magic(H / pool);
-    const size_t lds = (size_t)256 * (vw > 1 ? g.V : (g.V | 1)) * sizeof(float);
+    const size_t lds = (size_t)WINB * (vw > 1 ? g.V : (g.V | 1)) * sizeof(float);
     const dim3 grid((unsigned)((size_t)nb * chunks));
     // everything else on a one-segment row (odd T, e.g. the reference's 313 frames): 16-byte chunks of the block's flat output
     const bool flat = !row && vw < 4 && g.NS == 1 && al(out, 16) && al(E.argmax, 4) && al(E.xmask, 16);
     E.mT = div_magic(T);
     E.mPP = div_magic(MODE == 2 ? E.prev_pool : 1);
     if (flat) {
-        const size_t lds_f = (size_t)256 * g.V * sizeof(float);      // LDS row stride V (as VW > 1)
-        hipLaunchKernelGGL((spec_inv_kernel<MODE, 4, false, true>), grid, dim3(256), lds_f, st, S, out, C, H, T, g.V, g.NB,
+        const size_t lds_f = (size_t)WINB * g.V * sizeof(float);      // LDS row stride V (as VW > 1)
+        hipLaunchKernelGGL((spec_inv_kernel<MODE, 4, false, true, FN>), grid, dim3(NTHR), lds_f, st, S, out, C, H, T, g.V, g.NB,
                            chunks, WPB, g.NS, E);
     } else if (row)
-        hipLaunchKernelGGL((spec_inv_kernel<MODE, 4, true>), grid, dim3(256), lds, st, S, out, C, H, T, g.V, g.NB, chunks, WPB, g.NS, E);
+        hipLaunchKernelGGL((spec_inv_kernel<MODE, 4, true, false, FN>), grid, dim3(NTHR), lds, st, S, out, C, H, T, g.V, g.NB, chunks, WPB, g.NS, E);
     else if (vw == 4)
-        hipLaunchKernelGGL((spec_inv_kernel<MODE, 4>), grid, dim3(256), lds, st, S, out, C, H, T, g.V, g.NB, chunks, WPB, g.NS, E);
+        hipLaunchKernelGGL((spec_inv_kernel<MODE, 4, false, false, FN>), grid, dim3(NTHR), lds, st, S, out, C, H, T, g.V, g.NB, chunks, WPB, g.NS, E);
     else if (vw == 2)
-        hipLaunchKernelGGL((spec_inv_kernel<MODE, 2>), grid, dim3(256), lds, st, S, out, C, H, T, g.V, g.NB, chunks, WPB, g.NS, E);
+        hipLaunchKernelGGL((spec_inv_kernel<MODE, 2, false, false, FN>), grid, dim3(NTHR), lds, st, S, out, C, H, T, g.V, g.NB, chunks, WPB, g.NS, E);
     else
-        hipLaunchKernelGGL((spec_inv_kernel<MODE, 1>), grid, dim3(256), lds, st, S, out, C, H, T, g.V, g.NB, chunks, WPB, g.NS, E);
+        hipLaunchKernelGGL((spec_inv_kernel<MODE, 1, false, false, FN>), grid, dim3(NTHR), lds, st, S, out, C, H, T, g.V, g.NB, chunks, WPB, g.NS, E);
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
+}
+template <int MODE>
+static int run_spec_inv(const float* S, float* out, int nb, int C, int H, int T, const FftGeom& g, InvEpi E,
+                        hipStream_t st) {
+    return g.FN == 128 ? run_spec_inv_n<MODE, 128>(S, out, nb, C, H, T, g, E, st)
+                       : run_spec_inv_n<MODE, 64>(S, out, nb, C, H, T, g, E, st);
 }
 
 template <class C>
@@ -838,8 +971,12 @@ static int pack_fconv(const ConvArgs& a, Ptr2 w, int transposed, float* wf, hipS
     const long long per_wf = (long long)C::COUT * C::CIN * C::KW;
     const long long total = per_wf * a.nbr;
     const int blocks = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(pack_freq_weights_kernel, dim3(blocks), dim3(256), 0, st, w, wf, C::CIN, C::COUT, C::KW, a.kw,
-                       C::COB, C::CK, C::MT, C::WM, transposed, per_wf, a.nbr);
+    if (C::DILMAX == FDIL128)
+        hipLaunchKernelGGL(pack_freq_weights_kernel<128>, dim3(blocks), dim3(256), 0, st, w, wf, C::CIN, C::COUT, C::KW, a.kw,
+                           C::COB, C::CK, C::MT, C::WM, transposed, per_wf, a.nbr);
+    else
+        hipLaunchKernelGGL(pack_freq_weights_kernel<64>, dim3(blocks), dim3(256), 0, st, w, wf, C::CIN, C::COUT, C::KW, a.kw,
+                           C::COB, C::CK, C::MT, C::WM, transposed, per_wf, a.nbr);
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
 }
@@ -865,10 +1002,14 @@ static int run_fconv(const ConvArgs& a, const FftGeom& g, Ptr2 w, int transposed
     A.prev_pool = 1;
     A.B = g.Bs;
     A.T = g.P;
-    A.N = g.nb * FS;
-    A.F = FS;
+    A.N = g.nb * g.FS;
+    A.F = g.FS;
     A.dil = g.NB;
     A.ncb = ceil_div(g.P, C::WB);
+    if ((C::DILMAX == FDIL128) != (g.FN == 128) || g.NB > C::DILMAX) {
+        set_error("conv (fft): tile configuration and window length disagree (FN %d, NB %d)", g.FN, g.NB);
+        return ZNS_ERR_ARG;
+    }
     // two-kind layout: consecutive (sample, slot) items per workgroup (one block per item, 16-byte aligned plain stores): the
     // largest of 4 / 3 / 2 that divides the items and still leaves a workgroup for every CU (ZNS_TUNE_IPW overrides: tuning)
     A.ipw = 1;
@@ -904,7 +1045,7 @@ static int fft_fwd_t(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float
     float* s_in = xspec ? xspec : (float*)(base + L.s_in);   // kept by the caller for backward-weights when given
     float* s_out = (float*)(base + L.s_out);
     float* wf = (float*)(base + L.wf);
-    int rc = run_spec_fwd(x, s_in, g.nb, a.cin, a.H, a.T, g, a.kw / 2, FN, 1.f, st);
+    int rc = run_spec_fwd(x, s_in, g.nb, a.cin, a.H, a.T, g, a.kw / 2, g.FN, 1.f, st);
     if (rc) return rc;
     rc = run_fconv<C>(a, g, w, 0, s_in, s_out, wf, wpk, 0, st);
     if (rc) return rc;
@@ -933,7 +1074,7 @@ static int fft_dgrad_t(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, co
     float* wf = (float*)(base + L.wf);
     int rc = ZNS_OK;
     if (dzspec) s_in = const_cast<float*>(dzspec);           // written by the preceding backward-weights call
-    else rc = run_spec_fwd(dz, s_in, g.nb, a.cout, a.H, a.T, g, a.kw / 2, FN, 1.f, st);
+    else rc = run_spec_fwd(dz, s_in, g.nb, a.cout, a.H, a.T, g, a.kw / 2, g.FN, 1.f, st);
     if (rc) return rc;
     rc = run_fconv<C>(a, g, w, 1, s_in, s_out, wf, wpk, 1, st);
     if (rc) return rc;
@@ -957,10 +1098,10 @@ static int fft_wgrad_t(const ConvArgs& a, const float* dz, const float* x, MPtr2
     float* slab = (float*)(base + L.slab);
     int rc = ZNS_OK;
     if (xspec) sx = const_cast<float*>(xspec);                                         // saved by the forward call
-    else rc = run_spec_fwd(x, sx, g.nb, a.cin, a.H, a.T, g, a.kw / 2, FN, 1.f, st);   // windows of the input: (xr, xi, xr+xi)
+    else rc = run_spec_fwd(x, sx, g.nb, a.cin, a.H, a.T, g, a.kw / 2, g.FN, 1.f, st);   // windows of the input: (xr, xi, xr+xi)
     if (rc) return rc;
     if (dzspec_out)   // one pass over dZ: overlapped windows for the backward-data call + the zero-padded V-blocks
-        rc = run_spec_fwd(dz, dzspec_out, g.nb, a.cout, a.H, a.T, g, a.kw / 2, FN, 1.f, st, sz);
+        rc = run_spec_fwd(dz, dzspec_out, g.nb, a.cout, a.H, a.T, g, a.kw / 2, g.FN, 1.f, st, sz);
     else
         rc = run_spec_fwd(dz, sz, g.nb, a.cout, a.H, a.T, g, 0, g.V, -1.f, st);  // zero-padded V-blocks of dZ: (r, i, r-i)
     if (rc) return rc;
@@ -973,10 +1114,10 @@ static int fft_wgrad_t(const ConvArgs& a, const float* dz, const float* x, MPtr2
     A.B = g.Bs;
     A.T = g.P;
     A.ncb = ceil_div(g.P, W::CW);
-    A.F = FS;
+    A.F = g.FS;
     A.dil = g.NB;
     A.KS = fwg_pick_ks<W>(a, g, &A.tiles_total, &A.tiles_per_split);
-    const long long blocks = (long long)W::NQG * (W::CIN / W::CIB) * (W::COUT / W::COB) * A.KS * a.nbr * FS;
+    const long long blocks = (long long)W::NQG * (W::CIN / W::CIB) * (W::COUT / W::COB) * A.KS * a.nbr * g.FS;
     const bool probe = probe_match(2, a.cin, a.cout, a.kh);
     const int slot = probe ? g_probe.count % g_probe.n : 0;
     if (probe) ZNS_HIP(hipEventRecord(g_probe.start[slot], st));
@@ -984,9 +1125,14 @@ static int fft_wgrad_t(const ConvArgs& a, const float* dz, const float* x, MPtr2
     ZNS_LAUNCH_CHECK();
     if (probe) { ZNS_HIP(hipEventRecord(g_probe.stop[slot], st)); ++g_probe.count; }
     const int rblocks = a.nbr * a.cout * (a.cin / 32);
-    hipLaunchKernelGGL(wgrad_spec_reduce_kernel, dim3(rblocks + a.nbr * a.cout), dim3(128),
-                       (size_t)32 * a.kh * a.kw * sizeof(float), st, (const float*)slab, dw, A.KS, a.cout, a.cin, a.kh, a.kw,
-                       accumulate, a.nbr, (const float*)sz, db, g.Bs, g.P, rblocks);
+    if (g.FN == 128)
+        hipLaunchKernelGGL(wgrad_spec_reduce_kernel<128>, dim3(rblocks + a.nbr * a.cout), dim3(128),
+                           (size_t)32 * a.kh * a.kw * sizeof(float), st, (const float*)slab, dw, A.KS, a.cout, a.cin, a.kh, a.kw,
+                           accumulate, a.nbr, (const float*)sz, db, g.Bs, g.P, rblocks);
+    else
+        hipLaunchKernelGGL(wgrad_spec_reduce_kernel<64>, dim3(rblocks + a.nbr * a.cout), dim3(128),
+                           (size_t)32 * a.kh * a.kw * sizeof(float), st, (const float*)slab, dw, A.KS, a.cout, a.cin, a.kh, a.kw,
+                           accumulate, a.nbr, (const float*)sz, db, g.Bs, g.P, rblocks);
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
 }
@@ -1009,9 +1155,17 @@ static int with_cfg(const ConvArgs& a, int transposed, Fn&& f) {
             if (use_narrow<FF2, FF2a>(a)) return transposed ? f(cfg_tag<FD2a>{}) : f(cfg_tag<FF2a>{});
             return transposed ? f(cfg_tag<FD2>{}) : f(cfg_tag<FF2>{});
         case 3:
+            if (use_win128(a)) {
+                if (transposed) return use_narrow<FD3w, FD3wa>(a) ? f(cfg_tag<FD3wa>{}) : f(cfg_tag<FD3w>{});
+                return use_narrow<FF3w, FF3wa>(a) ? f(cfg_tag<FF3wa>{}) : f(cfg_tag<FF3w>{});
+            }
             if (transposed) return use_narrow<FD3, FD3a>(a) ? f(cfg_tag<FD3a>{}) : f(cfg_tag<FD3>{});
             return use_narrow<FF3, FF3a>(a) ? f(cfg_tag<FF3a>{}) : f(cfg_tag<FF3>{});
         case 4:
+            if (use_win128(a)) {
+                if (transposed) return use_narrow<FD4w, FD4wa>(a) ? f(cfg_tag<FD4wa>{}) : f(cfg_tag<FD4w>{});
+                return use_narrow<FF4w, FF4wa>(a) ? f(cfg_tag<FF4wa>{}) : f(cfg_tag<FF4w>{});
+            }
             if (transposed) return use_narrow<FD4, FD4a>(a) ? f(cfg_tag<FD4a>{}) : f(cfg_tag<FD4>{});
             return use_narrow<FF4, FF4a>(a) ? f(cfg_tag<FF4a>{}) : f(cfg_tag<FF4>{});
         case 5:
@@ -1046,14 +1200,15 @@ int fft_pack_layout(const ConvArgs& a, int transposed) {
     if (fft_layer_of(a) < 0) return 0;
     int id = 0;
     with_cfg(a, transposed, [&](auto t) {
-        id = pack_layout_id<typename decltype(t)::type>(1, transposed);
+        typedef typename decltype(t)::type Cfg;
+        id = pack_layout_id<Cfg>(Cfg::DILMAX == FDIL128 ? 3 : 1, transposed);   // family 3: 128-point windows (192 slots)
         return ZNS_OK;
     });
     return id;
 }
 size_t fft_pack_bytes(const ConvArgs& a, int transposed) {
     (void)transposed;
-    return fft_layer_of(a) < 0 ? 0 : (size_t)a.nbr * FS * a.cout * a.cin * a.kh * sizeof(float);
+    return fft_layer_of(a) < 0 ? 0 : (size_t)a.nbr * geom(a).FS * a.cout * a.cin * a.kh * sizeof(float);
 }
 int fft_pack(const ConvArgs& a, Ptr2 w, int transposed, float* dst, hipStream_t st) {
     return with_cfg(a, transposed, [&](auto t) { return pack_fconv<typename decltype(t)::type>(a, w, transposed, dst, st); });
