@@ -42,18 +42,30 @@ LAYER_GEOM = {"cv2": (64, 64, 7, 13, 96), "cv3": (64, 128, 5, 15, 32), "cv4": (1
               "cv5": (128, 256, 3, 19, 8), "cv6": (256, 256, 5, 21, 8)}   # cin, cout, kh, kw, H
 
 
+def window_length(layer: str, frames: int) -> int:
+    """Overlap-save window of `layer` at this row length, as the library picks it (csrc/zns_conv_fft.hip: use_win128):
+    128 samples for cv3 / cv4 where that needs fewer frequency-windows per row than 64-sample windows, else 64."""
+    kw = LAYER_GEOM[layer][3]
+    if layer in ("cv3", "cv4") and 2 * -(-frames // (129 - kw)) < -(-frames // (65 - kw)):
+        return 128
+    return 64
+
+
 def spectral_flop(layer: str, useful: bool, frames: int = T, samples: int = 2 * B) -> float:
     """FLOP of ONE pass (fwd, dgrad or wgrad) of `layer` in the frequency-domain form over `samples` spectrograms of
-    `frames` columns (default: both branches, B=16, T=512): 32 frequencies x 3 real GEMMs (Karatsuba) of
+    `frames` columns (default: both branches, B=16, T=512): FN/2 frequencies x 3 real GEMMs (Karatsuba) of
     cout x (cin*kh) per window position (executed); frequency slot 0 (DC + Nyquist, both real) needs only two of its
-    three (useful).  Rows longer than 12 windows run as NS segments of NB windows.  Tile padding is not counted."""
+    three (useful).  Rows longer than 12 (64-point) / 6 (128-point) windows run as NS segments of NB windows.  Tile
+    padding is not counted."""
     cin, cout, kh, kw, H = LAYER_GEOM[layer]
-    V = 64 - kw + 1
+    fn = window_length(layer, frames)
+    V = fn - kw + 1
     nbt = -(-frames // V)
-    ns = -(-nbt // 12)
+    ns = -(-nbt // (12 if fn == 64 else 6))
     nb = -(-nbt // ns)
     P = H * nb * ns
-    slots = (31 * 3 + 2) if useful else 32 * 3
+    ff = fn // 2
+    slots = ((ff - 1) * 3 + 2) if useful else ff * 3
     return 2.0 * slots * cout * cin * kh * P * samples
 
 
@@ -65,8 +77,9 @@ def exec_flop(frames: int, samples: int) -> float:
 
 # MFMA FLOP actually executed per step: cv2..cv6 in the frequency domain (3 passes), cv7/cv8 direct (3 passes)
 EXEC_FLOP = exec_flop(T, 2 * B)
-# dominant kernel (profiles/): the frequency-domain forward GEMM-conv of cv4 (conv_core<128,128,1x9 taps, 12-wave HET layout>)
-PROBE = dict(kind=0, cin=128, cout=128, kh=9, name="conv_core<spectral cv4 forward: 96 real 128x1152 GEMM-convs per sample, 9 row taps>",
+# dominant kernel (profiles/): the frequency-domain forward GEMM-conv of cv4 (conv_core<128,128,1x9 taps>: 128-point windows,
+# 192 slots per sample, four waves of (1 channel tile x 5 column tiles))
+PROBE = dict(kind=0, cin=128, cout=128, kh=9, name="conv_core<spectral cv4 forward: 192 real 128x1152 GEMM-convs per sample (128-point windows), 9 row taps>",
              flop=spectral_flop("cv4", True),
              # HBM bytes per launch from separate rocprofv3 --pmc passes, NOT measured by this run: 2 x FETCH_SIZE (gfx950
              # counts the 128-B requests of 16-byte loads as 64 B) + WRITE_SIZE of this kernel's row in PROBE_PMC_FILE.
@@ -628,7 +641,15 @@ def main():
     dt = float(tmax.item())
 
     comm = {}
+    replicas_identical = None
     if world > 1:
+        # every rank stepped on its OWN batch: equal parameters afterwards mean the gradient all-reduce (and the initial
+        # broadcast) did their job.  Bit patterns summed as integers, gathered, compared on rank 0 -- before the probe
+        # below lets the replicas drift.
+        csum = trainer.flat_p.view(torch.int32).to(torch.int64).sum().reshape(1)
+        sums = [torch.zeros_like(csum) for _ in range(world)]
+        torch.distributed.all_gather(sums, csum)
+        replicas_identical = all(int(s.item()) == int(sums[0].item()) for s in sums)
         # exposed communication: the same K steps with the gradient all-reduce switched off (replicas drift apart, which
         # is irrelevant after the timed region); exposed = with - without.  Every rank runs it: same barriers.
         reducer, trainer.reducer = trainer.reducer, None
@@ -644,7 +665,8 @@ def main():
         torch.distributed.all_reduce(tnc, op=torch.distributed.ReduceOp.MAX)
         dt_nc = float(tnc.item())
         comm = {"comm_exposed_ms": (dt - dt_nc) / K * 1e3, "ms_per_step_without_allreduce": dt_nc / K * 1e3,
-                "allreduce_bytes": trainer.n_flat * 4, "allreduce_buckets": len(trainer.buckets), **stream_choice}
+                "allreduce_bytes": trainer.n_flat * 4, "allreduce_buckets": len(trainer.buckets),
+                "replicas_identical_after_timed_region": replicas_identical, **stream_choice}
         phase("exposed-communication probe")
 
     if rank == 0:

@@ -81,8 +81,11 @@ size_t zns_conv2d_packed_bytes(int nbr, int B, int T, int cin, int cout, int kh,
 int zns_conv2d_pack_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, int transposed,
                         const float* const* w, float* dst, size_t dst_bytes, void* stream);
 
+/* x: [nbr*B, cin, H, T], the branches' samples back to back.  x1 (nullable, first layer -- cin == 1 -- of a two-branch
+ * stack only): the reference hands Pretext_CNN two separate tensors (models.py:119-122, pretext.py:482); with x1 given, x
+ * holds branch 0's B samples and x1 branch 1's, and nothing is concatenated. */
 int zns_conv2d_fwd_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, int pool,
-                       const float* x, const float* const* w, const float* const* bias,
+                       const float* x, const float* x1, const float* const* w, const float* const* bias,
                        float* y, uint8_t* argmax,
                        float drop_p, uint32_t seed, int layer,
                        float* xspec /* nullable: receives the input spectrum, see zns_conv2d_spectrum_bytes */,
@@ -109,7 +112,8 @@ int zns_conv2d_dgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int k
 /* Backward-weights: dw[br] (+)= sum_{b,h,t} dz (x) shifted x ; db[br] (+)= sum dz.
  * accumulate != 0 adds into dw/db (gradient accumulation), else overwrites. */
 int zns_conv2d_wgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H,
-                         const float* dz, const float* x, float* const* dw, float* const* db,
+                         const float* dz, const float* x, const float* x1 /* as in zns_conv2d_fwd_f32 */,
+                         float* const* dw, float* const* db,
                          int accumulate, const float* xspec /* nullable: spectrum saved by the forward call */,
                          float* dzspec_out /* nullable: receives the dZ spectrum, see zns_conv2d_dz_spectrum_bytes */,
                          void* ws, size_t ws_bytes, void* stream);
@@ -119,9 +123,11 @@ int zns_conv2d_wgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int k
 int zns_head_fwd_f32(int nbr, int B, int T, int C, const float* h, const float* const* w,
                      const float* const* b, float* emb, void* stream);
 /* Given demb: dz8 = demb*emb*(1-emb) * w[c] * (h != 0) * inv_keep  (grad w.r.t. cv8 raw output),
- * dw[c] (+)= sum demb*emb*(1-emb)*h, db (+)= sum demb*emb*(1-emb). */
+ * dw[c] (+)= sum demb*emb*(1-emb)*h, db (+)= sum demb*emb*(1-emb).
+ * demb1 (nullable, nbr == 2): branch 1's gradient rows when autograd hands the two embeddings' gradients as separate
+ * tensors (demb then holds branch 0's B rows); NULL: demb is [nbr*B, T]. */
 int zns_head_bwd_f32(int nbr, int B, int T, int C, const float* h, const float* emb, const float* demb,
-                     const float* const* w, float inv_keep, float* dz, float* const* dw, float* const* db,
+                     const float* demb1, const float* const* w, float inv_keep, float* dz, float* const* dw, float* const* db,
                      int accumulate, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ Down_CNN combine (models.py:144-148) */
@@ -132,10 +138,19 @@ int zns_down_bwd_f32(const float* a, const float* p, const float* dout, size_t n
 /* ------------------------------------------------------------------ NT-Xent (loss_functions.py:24-55)
  * a, p: [rows, D] (rows <= batch_len, 1 <= rows <= 2048: config.yaml's batch_size is 16).  out3 (device, 3 floats): loss,
  * mean anchor/positive cosine, mean anchor/negative cosine -- all divided by batch_len as the reference does.
- * ga/gp (nullable): d(loss*grad_scale)/da, /dp.  ws: zns_ntxent_workspace_bytes(rows) bytes of device scratch. */
+ * loss_out (nullable): the loss once more, as a device scalar of its own (a framework that needs the loss as a separate
+ * tensor gets it without a copy kernel).  ga/gp (nullable): d(loss*grad_scale)/da, /dp.
+ * ws: zns_ntxent_workspace_bytes(rows) bytes of device scratch (float64 tables: see csrc/zns_small.hip). */
 size_t zns_ntxent_workspace_bytes(int rows);
 int zns_ntxent_f32(const float* a, const float* p, int rows, int D, int batch_len, float tau,
-                   float* out3, float* ga, float* gp, float grad_scale, void* ws, size_t ws_bytes, void* stream);
+                   float* out3, float* loss_out, float* ga, float* gp, float grad_scale, void* ws, size_t ws_bytes,
+                   void* stream);
+
+/* y = x * scale[0] with `scale` a DEVICE scalar: the factor autograd hands a loss node's backward (`loss.backward()`:
+ * ones; `(2 * loss).backward()`: 2), applied without a host read-back.  Two arrays per launch (NT-Xent: ga, gp); n1 = 0
+ * for one.  In place (y == x) is allowed. */
+int zns_scale_f32(const float* scale, const float* x0, float* y0, size_t n0, const float* x1, float* y1, size_t n1,
+                  void* stream);
 
 /* BCELoss(mean) forward + backward (loader.py:16, epochs.py:61): loss (device scalar), dout nullable */
 int zns_bce_f32(const float* out, const float* target, size_t n, float* loss, float* dout,

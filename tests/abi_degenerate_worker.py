@@ -70,7 +70,7 @@ def conv():
 
     def fwd(ov):
         a = {**g, "pool": pool, "layer": 1, **ov}
-        return L.zns_conv2d_fwd_f32(*[a[k] for k in geo], a["pool"], dp(x), PP(*[t.data_ptr() for t in w]),
+        return L.zns_conv2d_fwd_f32(*[a[k] for k in geo], a["pool"], dp(x), None, PP(*[t.data_ptr() for t in w]),
                                     PP(*[t.data_ptr() for t in b]), dp(y), dp(am), C.c_float(0.1), 5, a["layer"],
                                     None, None, dp(ws), ws.numel(), None)
 
@@ -81,7 +81,7 @@ def conv():
 
     def wgrad(ov):
         a = {**g, "accumulate": 1, **ov}
-        return L.zns_conv2d_wgrad_f32(*[a[k] for k in geo], dp(dz), dp(x), PP(*[t.data_ptr() for t in dw]),
+        return L.zns_conv2d_wgrad_f32(*[a[k] for k in geo], dp(dz), dp(x), None, PP(*[t.data_ptr() for t in dw]),
                                       PP(*[t.data_ptr() for t in db]), a["accumulate"], None, None, dp(ws), ws.numel(),
                                       None)
 
@@ -105,7 +105,7 @@ def conv():
             L.zns_set_impl(prev)
     sweep("conv2d_pack", pack, geo, {"transposed": (0,)})
     # a workspace one byte short is an error, not an overrun
-    rc = L.zns_conv2d_fwd_f32(nbr, B, T, cin, cout, kh, kw, H, pool, dp(x), PP(*[t.data_ptr() for t in w]),
+    rc = L.zns_conv2d_fwd_f32(nbr, B, T, cin, cout, kh, kw, H, pool, dp(x), None, PP(*[t.data_ptr() for t in w]),
                               PP(*[t.data_ptr() for t in b]), dp(y), dp(am), C.c_float(0.1), 5, 1, None, None, dp(ws), 16,
                               None)
     assert rc != 0, "16-byte workspace accepted"
@@ -131,7 +131,7 @@ def small():
 
     def head_bwd(ov):
         a = {**g, "accumulate": 0, **ov}
-        return L.zns_head_bwd_f32(a["nbr"], a["B"], a["T"], a["C"], dp(h), dp(emb), dp(demb),
+        return L.zns_head_bwd_f32(a["nbr"], a["B"], a["T"], a["C"], dp(h), dp(emb), dp(demb), None,
                                   PP(*[t.data_ptr() for t in w]), C.c_float(1.0), dp(dz), PP(*[t.data_ptr() for t in dw]),
                                   PP(*[t.data_ptr() for t in db]), a["accumulate"], dp(ws), ws.numel(), None)
 

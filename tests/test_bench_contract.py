@@ -14,11 +14,14 @@ def test_work_accounting_matches_the_survey():
     import bench
     # 2.035e13 FLOP per step in the direct form (fwd + both backward passes, no cv1 dgrad)
     assert abs(bench.STEP_FLOP / 2.035e13 - 1) < 2e-3
-    # frequency-domain cv4 forward: 95 useful real GEMM-convs of 128 x (128*9) per window position, 352 positions, 32 samples
-    assert bench.spectral_flop("cv4", True) == 2.0 * 95 * 128 * 128 * 9 * 352 * 32
-    assert bench.spectral_flop("cv4", False) == 2.0 * 96 * 128 * 128 * 9 * 352 * 32
+    # frequency-domain cv4 forward on 128-point windows: 63 * 3 + 2 = 191 useful real GEMM-convs of 128 x (128*9) per window
+    # position, 32 rows x 5 windows = 160 positions, 32 samples
+    assert bench.window_length("cv4", 512) == 128 and bench.window_length("cv4", 40) == 64 and bench.window_length("cv6", 512) == 64
+    assert bench.spectral_flop("cv4", True) == 2.0 * 191 * 128 * 128 * 9 * 160 * 32
+    assert bench.spectral_flop("cv4", False) == 2.0 * 192 * 128 * 128 * 9 * 160 * 32
+    assert bench.spectral_flop("cv6", False) == 2.0 * 96 * 256 * 256 * 5 * 96 * 32          # 64-point windows: 12 per row of 8
     assert bench.PROBE["flop"] == bench.spectral_flop("cv4", True)
-    assert 2.5e12 < bench.EXEC_FLOP < 2.7e12
+    assert 2.4e12 < bench.EXEC_FLOP < 2.6e12
     assert bench.host_cores() >= 1
 
 
@@ -87,6 +90,37 @@ def test_bench_two_ranks_dry_run_on_one_gpu():
     assert r["config"]["ms_per_step_without_allreduce"] > 0 and r["config"]["allreduce_buckets"] >= 3
     assert "cpu_baseline" not in r
     assert abs(r["value"] - 2 * 1000.0 / r["ms_per_step"]) < 1e-6 * r["value"]      # whole-job steps/s
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_dry_run_on_one_gpu():
+    """BASELINE configs[4]'s shape of launch -- eight ranks, one process each, as the driver starts them -- on this box's one
+    GPU over gloo: eight process-group members, six buckets in flight per step, eight parameter broadcasts, the
+    exposed-communication probe, and afterwards eight replicas that stepped on eight different batches and hold bit-identical
+    parameters.  A functional dry run of the first 8-GPU run, never a performance number."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, ZNS_BENCH_BACKEND="gloo", ZNS_BENCH_CU_MASK="off")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "8", "--steps", "2", "--warmup", "1", "--no-extras"],
+                         capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    c = r["config"]
+    assert r["n_gpus"] == 8 and c["global_batch"] == 128 and c["parallelism"] == "dp8" and r["scaling"] == "weak"
+    assert c["allreduce_buckets"] == 6 and c["allreduce_bytes"] == 26819202 * 4
+    assert "comm_exposed_ms" in c and c["ms_per_step_without_allreduce"] > 0
+    assert c["replicas_identical_after_timed_region"] is True
+    assert abs(r["value"] - 8 * 1000.0 / r["ms_per_step"]) < 1e-6 * r["value"]
+    for rk in range(8):
+        for ph in ("init_process_group(gloo) ok", "trainer built, rank 0's parameters broadcast ok", "timed region (2 steps", "done ok"):
+            assert f"[rank {rk}] {ph}" in out.stderr, (rk, ph, out.stderr[-2000:])
 
 
 @pytest.mark.gpu

@@ -28,13 +28,20 @@ def synth(B, T, seed):
     return x.clamp_(-20.72, 3.0).to(DEV)
 
 
-def run(impl, model, x, B, drop_p=0.0, seed=0, backward=True):
+def run(impl, model, x, B, drop_p=0.0, seed=0, backward=True, replay=None, want_saved=False):
+    """One forward (+ backward) on kernel family `impl`.  replay = (acts, argm, emb) of ANOTHER family's forward: the backward
+    then takes that forward's decisions (arg-max maps, zero patterns) and saved activations, so the two families' gradients
+    differ by their convolution arithmetic alone."""
     from zeronotesamba_amd import _lib, _ops
     P = _ops.StackParams.from_flat(model.anchor.stack_params() + model.postve.stack_params(), 2)
     prev = _lib.lib().zns_set_impl(impl)
     try:
         with torch.no_grad():
             emb, acts, argm = _ops.stack_forward(x, P, B, drop_p, seed, save=True)
+            saved = (acts, argm, emb)
+            if replay is not None:
+                acts, argm, emb = replay
+                argm = {k: v for k, v in argm.items() if k < 100}     # arg-max maps only: the other family's saved spectra stay out
             grads = None
             if backward:
                 demb = torch.cos(torch.arange(emb.numel(), device=DEV, dtype=torch.float32) * 0.37).reshape(emb.shape)
@@ -44,7 +51,35 @@ def run(impl, model, x, B, drop_p=0.0, seed=0, backward=True):
         torch.cuda.synchronize()
     finally:
         _lib.lib().zns_set_impl(prev)
+    if want_saved:
+        return emb, acts, grads, saved
     return emb, acts, grads
+
+
+def default_against_direct(model, x, B, T):
+    """The default (frequency-domain) path against the direct MFMA kernels: embeddings and every layer's activations at the
+    north_star tolerance; gradients twice -- each family on its OWN decisions (flip tolerant: max-pool / ReLU near-ties,
+    DESIGN.md section 6: one flipped element moves a weight gradient by ~1e-2 of its norm), and the strict one: the direct
+    kernels' backward on the default forward's decisions and activations, where only the two families' convolution
+    arithmetic is left (1e-4 of every parameter gradient's norm)."""
+    from zeronotesamba_amd import _lib
+    e_f, a_f, g_f, saved_f = run(_lib.ZNS_IMPL_AUTO, model, x, B, want_saved=True)
+    e_d, a_d, g_d = run(_lib.ZNS_IMPL_DIRECT, model, x, B)
+    assert tuple(e_f.shape) == (2 * B, T)
+    assert (e_f - e_d).abs().max().item() < 1e-4
+    for li in range(8):
+        scale = a_d[li].abs().max().item()
+        assert (a_f[li] - a_d[li]).abs().max().item() <= 1e-4 * scale, f"layer {li + 1} activations"
+    for gf, gd in zip(g_f, g_d):
+        rel = ((gf - gd).norm() / gd.norm().clamp_min(1e-30)).item()
+        assert rel < 3e-2, rel
+    _, _, g_r = run(_lib.ZNS_IMPL_DIRECT, model, x, B, replay=saved_f)
+    worst = 0.0
+    for gf, gr in zip(g_f, g_r):
+        worst = max(worst, ((gf - gr).norm() / gr.norm().clamp_min(1e-30)).item())
+    print("B=%d T=%d: default vs direct backward on the same decisions, worst per-parameter gradient rel L2 %.2e" % (B, T, worst))
+    assert worst <= 1e-4, worst
+    return e_f, a_f, g_f
 
 
 @pytest.mark.parametrize("T", [512, 313, 626])
@@ -53,16 +88,7 @@ def test_spectral_vs_direct_full_size(T):
     B = 16
     model = build()
     x = synth(B, T, 1)
-    e_f, a_f, g_f = run(_lib.ZNS_IMPL_AUTO, model, x, B)
-    e_d, a_d, g_d = run(_lib.ZNS_IMPL_DIRECT, model, x, B)
-    assert tuple(e_f.shape) == (2 * B, T)
-    assert (e_f - e_d).abs().max().item() < 1e-4                     # north_star tolerance on the embeddings
-    for li in range(8):
-        scale = a_d[li].abs().max().item()
-        assert (a_f[li] - a_d[li]).abs().max().item() <= 1e-4 * scale, f"layer {li + 1} activations"
-    for gf, gd in zip(g_f, g_d):
-        rel = ((gf - gd).norm() / gd.norm().clamp_min(1e-30)).item()
-        assert rel < 1e-2, rel                                         # max-pool near-tie flips, see DESIGN.md section 6
+    e_f, a_f, g_f = default_against_direct(model, x, B, T)
     # bitwise repeatability (split-K slabs and spectra are reduced in a fixed order, no float atomics)
     e2, _, g2 = run(_lib.ZNS_IMPL_AUTO, model, x, B)
     assert torch.equal(e_f, e2)
@@ -114,18 +140,9 @@ def test_finetune_shape_long_clip_segmented_rows(B, T):
     from zeronotesamba_amd import _lib
     model = build(3)
     x = synth(B, T, 4)
-    e_a, a_a, g_a = run(_lib.ZNS_IMPL_AUTO, model, x, B)
-    e_d, a_d, g_d = run(_lib.ZNS_IMPL_DIRECT, model, x, B)
+    e_a, a_a, g_a = default_against_direct(model, x, B, T)
     e_n, _, _ = run(_lib.ZNS_IMPL_NAIVE, model, x, B, backward=False)
-    assert tuple(e_a.shape) == (2 * B, T)
     assert (e_a - e_n).abs().max().item() < 1e-4
-    assert (e_a - e_d).abs().max().item() < 1e-4
-    for li in range(8):
-        scale = a_d[li].abs().max().item()
-        assert (a_a[li] - a_d[li]).abs().max().item() <= 1e-4 * scale, f"layer {li + 1} activations"
-    for ga, gd in zip(g_a, g_d):
-        rel = ((ga - gd).norm() / gd.norm().clamp_min(1e-30)).item()
-        assert rel < 1e-2, rel
     # the segmented path is the frequency-domain one: a saved input spectrum exists for cv2..cv6
     assert _lib.lib().zns_conv2d_spectrum_bytes(2, B, T, 128, 128, 9, 17, 32) > 0
 
@@ -136,19 +153,9 @@ def test_ragged_shapes_spectral_vs_direct(B, T):
     a segment boundary (cv2: 12 windows of 52 = 624 > 577 > 11*52; cv6: 577 = 13.1 windows -> 2 segments), T = 529 =
     one sample past 12 windows of cv6 (44*12 = 528) and a long row with 3 segments.  Default (frequency-domain) path
     against the direct MFMA kernels: activations of every layer, embeddings, every gradient."""
-    from zeronotesamba_amd import _lib
     model = build(11)
     x = synth(B, T, 100 + T)
-    e_f, a_f, g_f = run(_lib.ZNS_IMPL_AUTO, model, x, B)
-    e_d, a_d, g_d = run(_lib.ZNS_IMPL_DIRECT, model, x, B)
-    assert tuple(e_f.shape) == (2 * B, T)
-    assert (e_f - e_d).abs().max().item() < 1e-4
-    for li in range(8):
-        scale = a_d[li].abs().max().item()
-        assert (a_f[li] - a_d[li]).abs().max().item() <= 1e-4 * scale, f"layer {li + 1} activations"
-    for gf, gd in zip(g_f, g_d):
-        rel = ((gf - gd).norm() / gd.norm().clamp_min(1e-30)).item()
-        assert rel < 1e-2, rel
+    default_against_direct(model, x, B, T)
 
 
 def test_clmr_style_shared_branch_module_api():

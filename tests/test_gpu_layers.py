@@ -315,13 +315,13 @@ def test_unsupported_and_bad_arguments_fail_loudly():
     b = [torch.zeros(5, device=dev)]
     y = torch.zeros(1, 5, 8, 16, device=dev)
     ws = _ops.workspace(1 << 20, dev)
-    rc = L.zns_conv2d_fwd_f32(1, 1, 16, 3, 5, 3, 3, 8, 1, x.data_ptr(), _ops._pp(w), _ops._pp(b), y.data_ptr(), None,
+    rc = L.zns_conv2d_fwd_f32(1, 1, 16, 3, 5, 3, 3, 8, 1, x.data_ptr(), None, _ops._pp(w), _ops._pp(b), y.data_ptr(), None,
                               0.0, 0, 0, None, None, ws.data_ptr(), ws.numel(), _ops.stream_ptr())
     assert rc == -1 and b"no gfx950 kernel instance" in L.zns_last_error()
-    rc = L.zns_conv2d_fwd_f32(3, 1, 16, 1, 64, 3, 11, 96, 1, x.data_ptr(), _ops._pp(w), _ops._pp(b), y.data_ptr(),
+    rc = L.zns_conv2d_fwd_f32(3, 1, 16, 1, 64, 3, 11, 96, 1, x.data_ptr(), None, _ops._pp(w), _ops._pp(b), y.data_ptr(),
                               None, 0.0, 0, 0, None, None, ws.data_ptr(), ws.numel(), _ops.stream_ptr())
     assert rc == -1
-    rc = L.zns_conv2d_fwd_f32(1, 0, 16, 1, 64, 3, 11, 96, 1, x.data_ptr(), _ops._pp(w), _ops._pp(b), y.data_ptr(),
+    rc = L.zns_conv2d_fwd_f32(1, 0, 16, 1, 64, 3, 11, 96, 1, x.data_ptr(), None, _ops._pp(w), _ops._pp(b), y.data_ptr(),
                               None, 0.0, 0, 0, None, None, ws.data_ptr(), ws.numel(), _ops.stream_ptr())
     assert rc == -1 and b"empty" in L.zns_last_error()
 

@@ -482,3 +482,73 @@ def test_probe_is_single_owner():
         assert b"already armed" in L.zns_last_error()
     finally:
         assert L.zns_probe_arm(0, 0, 0, 0, None, None, 0) == 0
+
+
+def _kernel_names(fn, warm=2):
+    """Names of every GPU kernel `fn()` launches (torch.profiler, device activities only), after `warm` untraced calls."""
+    from torch.profiler import ProfilerActivity, profile
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+        fn()
+        torch.cuda.synchronize()
+    names = [e.name for e in prof.events() if str(getattr(e, "device_type", "")).endswith("CUDA")]
+    if not names:
+        pytest.skip("torch.profiler records no device kernels on this box")
+    return names
+
+
+@pytest.mark.parametrize("path", ["pretext", "finetune", "separate-inputs"])
+def test_module_path_launches_no_aten_kernels(path):
+    """The drop-in step as the reference writes it (pretext.py:475-492 / epochs.py:48-63: zero_grad, module forward on two
+    tensors, loss, backward, Adam) launches only this library's kernels: the branches' inputs go to the first layer as two
+    pointers (no torch.cat), the two embeddings come back as two tensors and their gradients are taken as they come (no
+    slice-backward fills), d(loss) is applied by zns_scale_f32 (no ATen multiply), the loss tensor is written by the kernel
+    (no clone).  The ONE exception is autograd's own root gradient of `loss.backward()` (a fill of one element)."""
+    from zeronotesamba_amd.epochs import bce_loss
+    from zeronotesamba_amd.models.loss_functions import NTXent
+    from zeronotesamba_amd.models.models import Down_CNN, Pretext_CNN
+    from zeronotesamba_amd.optim import Adam
+    torch.manual_seed(0)
+    B, T = (4, 64) if path != "finetune" else (1, 96)
+    g = torch.Generator().manual_seed(3)
+    both = (torch.randn((2, B, 1, 96, T), generator=g) * 3 - 6).clamp_(-20.72, 3.0).to(DEV)
+    if path == "separate-inputs":               # two tensors that are NOT halves of one buffer
+        anc, pos = both[0].clone(), torch.empty((B + 3, 1, 96, T), device=DEV)[3:].copy_(both[1])
+    else:
+        anc, pos = both[0], both[1]
+    if path == "finetune":
+        m = Down_CNN().to(DEV)
+        msk = torch.zeros((1, T), device=DEV)
+        msk[0, ::31] = 1.0
+    else:
+        m = Pretext_CNN().to(DEV)
+        crit = NTXent(B, 0.25)
+    opt = Adam(m.parameters(), lr=1e-6)
+
+    def step():
+        opt.zero_grad()
+        if path == "finetune":
+            loss = bce_loss(m(anc, pos), msk)
+        else:
+            a, p = m(anc, pos)
+            loss, _, _ = crit(a, p)
+        loss.backward()
+        opt.step()
+
+    names = _kernel_names(step)
+    ours = [n for n in names if "zns::" in n]
+    foreign = [n for n in names if "zns::" not in n and "Memcpy" not in n and "memcpy" not in n and "copyBuffer" not in n]
+    assert len(ours) > 40
+    fills = [n for n in foreign if "FillFunctor" in n]
+    other = [n for n in foreign if "FillFunctor" not in n]
+    assert not other, other
+    assert len(fills) <= 1, fills                # autograd's root gradient for loss.backward()
+    # and the two-pointer path computes what the stacked tensor computes
+    if path == "separate-inputs":
+        m.eval()
+        with torch.no_grad():
+            a1, p1 = m(anc, pos)
+            a2, p2 = m(both[0], both[1])
+        assert torch.equal(a1, a2) and torch.equal(p1, p2)

@@ -25,20 +25,21 @@ SIGNATURES = {
     "zns_conv2d_dz_spectrum_bytes": (C.c_size_t, [C.c_int] * 8),
     "zns_conv2d_packed_bytes": (C.c_size_t, [C.c_int] * 9 + [C.POINTER(C.c_int)]),
     "zns_conv2d_pack_f32": (C.c_int, [C.c_int] * 9 + [c_pp, c_fp, C.c_size_t, c_fp]),
-    "zns_conv2d_fwd_f32": (C.c_int, [C.c_int] * 9 + [c_fp, c_pp, c_pp, c_fp, c_fp, C.c_float, C.c_uint32, C.c_int,
+    "zns_conv2d_fwd_f32": (C.c_int, [C.c_int] * 9 + [c_fp, c_fp, c_pp, c_pp, c_fp, c_fp, C.c_float, C.c_uint32, C.c_int,
                                                      c_fp, c_fp, c_fp, C.c_size_t, c_fp]),
     "zns_conv2d_dgrad_f32": (C.c_int, [C.c_int] * 8 + [c_fp, c_pp, c_fp, c_fp, C.c_float, c_fp, C.c_int,
                                                        c_fp, c_fp, c_fp, C.c_size_t, c_fp]),
-    "zns_conv2d_wgrad_f32": (C.c_int, [C.c_int] * 8 + [c_fp, c_fp, c_pp, c_pp, C.c_int, c_fp, c_fp, c_fp,
+    "zns_conv2d_wgrad_f32": (C.c_int, [C.c_int] * 8 + [c_fp, c_fp, c_fp, c_pp, c_pp, C.c_int, c_fp, c_fp, c_fp,
                                                        C.c_size_t, c_fp]),
     "zns_head_fwd_f32": (C.c_int, [C.c_int] * 4 + [c_fp, c_pp, c_pp, c_fp, c_fp]),
-    "zns_head_bwd_f32": (C.c_int, [C.c_int] * 4 + [c_fp, c_fp, c_fp, c_pp, C.c_float, c_fp, c_pp, c_pp, C.c_int,
+    "zns_head_bwd_f32": (C.c_int, [C.c_int] * 4 + [c_fp, c_fp, c_fp, c_fp, c_pp, C.c_float, c_fp, c_pp, c_pp, C.c_int,
                                                    c_fp, C.c_size_t, c_fp]),
     "zns_down_fwd_f32": (C.c_int, [c_fp, c_fp, C.c_size_t, C.c_int, c_fp, c_fp]),
     "zns_down_bwd_f32": (C.c_int, [c_fp, c_fp, c_fp, C.c_size_t, C.c_int, c_fp, c_fp, c_fp]),
     "zns_ntxent_workspace_bytes": (C.c_size_t, [C.c_int]),
-    "zns_ntxent_f32": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_float, c_fp, c_fp, c_fp, C.c_float, c_fp,
+    "zns_ntxent_f32": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_float, c_fp, c_fp, c_fp, c_fp, C.c_float, c_fp,
                                  C.c_size_t, c_fp]),
+    "zns_scale_f32": (C.c_int, [c_fp, c_fp, c_fp, C.c_size_t, c_fp, c_fp, C.c_size_t, c_fp]),
     "zns_bce_f32": (C.c_int, [c_fp, c_fp, C.c_size_t, c_fp, c_fp, C.c_float, c_fp]),
     "zns_adam_step_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float,
                                     C.c_int, C.c_float, c_fp]),

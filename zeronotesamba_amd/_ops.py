@@ -203,7 +203,9 @@ def bump_version(t: torch.Tensor) -> None:
 
 
 def conv_fwd(li: int, nbr: int, B: int, T: int, x: torch.Tensor, w: Sequence[torch.Tensor],
-             b: Sequence[torch.Tensor], drop_p: float, seed: int, want_argmax: bool, ws: torch.Tensor):
+             b: Sequence[torch.Tensor], drop_p: float, seed: int, want_argmax: bool, ws: torch.Tensor,
+             x1: Optional[torch.Tensor] = None):
+    """x1 (first layer of a two-branch stack only): branch 1's samples when the branches' inputs are separate tensors."""
     name, cin, cout, kh, kw, pool = LAYERS[li]
     H = H_IN[li]
     y = torch.empty((nbr * B, cout, H // pool, T), dtype=torch.float32, device=x.device)
@@ -216,10 +218,11 @@ def conv_fwd(li: int, nbr: int, B: int, T: int, x: torch.Tensor, w: Sequence[tor
             nspec = _lib.lib().zns_conv2d_spectrum_bytes(nbr, B, T, cin, cout, kh, kw, H)
         if nspec:
             spec = torch.empty(nspec // 4, dtype=torch.float32, device=x.device)
-    same_device(x, (*w, *b, ws), name)
+    same_device(x, (*w, *b, ws, x1), name)
     wpk = packed_weights(li, False, nbr, B, T, w)
     with on_device(x):
-        rc = _lib.lib().zns_conv2d_fwd_f32(nbr, B, T, cin, cout, kh, kw, H, pool, x.data_ptr(), _pp(w), _pp(b),
+        rc = _lib.lib().zns_conv2d_fwd_f32(nbr, B, T, cin, cout, kh, kw, H, pool, x.data_ptr(),
+                                           x1.data_ptr() if x1 is not None else None, _pp(w), _pp(b),
                                            y.data_ptr(), am.data_ptr() if am is not None else None,
                                            float(drop_p), int(seed) & 0xFFFFFFFF, li,
                                            spec.data_ptr() if spec is not None else None,
@@ -250,12 +253,14 @@ def conv_dgrad(li: int, nbr: int, B: int, T: int, dz: torch.Tensor, w: Sequence[
 
 def conv_wgrad(li: int, nbr: int, B: int, T: int, dz: torch.Tensor, x: torch.Tensor, dw: Sequence[torch.Tensor],
                db: Sequence[torch.Tensor], accumulate: bool, ws: torch.Tensor,
-               xspec: Optional[torch.Tensor] = None, dzspec_out: Optional[torch.Tensor] = None) -> None:
+               xspec: Optional[torch.Tensor] = None, dzspec_out: Optional[torch.Tensor] = None,
+               x1: Optional[torch.Tensor] = None) -> None:
     name, cin, cout, kh, kw, pool = LAYERS[li]
     H = H_IN[li]
-    same_device(dz, (x, *dw, *db, xspec, dzspec_out, ws), name)
+    same_device(dz, (x, *dw, *db, xspec, dzspec_out, ws, x1), name)
     with on_device(dz):
-        rc = _lib.lib().zns_conv2d_wgrad_f32(nbr, B, T, cin, cout, kh, kw, H, dz.data_ptr(), x.data_ptr(), _pp(dw),
+        rc = _lib.lib().zns_conv2d_wgrad_f32(nbr, B, T, cin, cout, kh, kw, H, dz.data_ptr(), x.data_ptr(),
+                                             x1.data_ptr() if x1 is not None else None, _pp(dw),
                                              _pp(db), int(bool(accumulate)),
                                              xspec.data_ptr() if xspec is not None else None,
                                              dzspec_out.data_ptr() if dzspec_out is not None else None,
@@ -272,16 +277,41 @@ def dz_spectrum(li: int, nbr: int, B: int, T: int, device) -> Optional[torch.Ten
 
 
 def ntxent(a: torch.Tensor, p: torch.Tensor, rows: int, D: int, batch_len: int, tau: float, out3: torch.Tensor,
-           ga: Optional[torch.Tensor], gp: Optional[torch.Tensor], grad_scale: float = 1.0) -> None:
+           ga: Optional[torch.Tensor], gp: Optional[torch.Tensor], grad_scale: float = 1.0,
+           loss_out: Optional[torch.Tensor] = None) -> None:
     """zns_ntxent_f32 on a/p's device and current stream (scratch from workspace slot 2)."""
-    same_device(a, (p, out3, ga, gp), "NTXent (the reference moves anc_emb to the positives' device first, pretext.py:484)")
+    same_device(a, (p, out3, ga, gp, loss_out), "NTXent (the reference moves anc_emb to the positives' device first, pretext.py:484)")
     L = _lib.lib()
     ws = workspace(L.zns_ntxent_workspace_bytes(rows), a.device, slot=2)
     with on_device(a):
         rc = L.zns_ntxent_f32(a.data_ptr(), p.data_ptr(), rows, D, batch_len, float(tau), out3.data_ptr(),
+                              loss_out.data_ptr() if loss_out is not None else None,
                               ga.data_ptr() if ga is not None else None, gp.data_ptr() if gp is not None else None,
                               float(grad_scale), ws.data_ptr(), ws.numel(), stream_ptr(a.device))
     _lib.check(rc, "zns_ntxent_f32")
+
+
+def scale_by(scale: torch.Tensor, x0: torch.Tensor, x1: Optional[torch.Tensor] = None):
+    """x0 * scale (and x1 * scale) with `scale` a one-element DEVICE tensor -- the factor autograd hands a loss node's
+    backward -- as one launch of zns_scale_f32: no host read-back, no ATen kernel.  Returns new tensors."""
+    require_device(x0, "scale_by input")
+    s = scale.reshape(-1)
+    if s.numel() != 1 or s.dtype != torch.float32:
+        raise RuntimeError("zeronotesamba_amd: the loss gradient must be one float32 element")
+    x0 = x0.contiguous()
+    y0 = torch.empty_like(x0)
+    y1 = None
+    if x1 is not None:
+        x1 = x1.contiguous()
+        y1 = torch.empty_like(x1)
+    same_device(x0, (s, x1), "scale_by")
+    with on_device(x0):
+        rc = _lib.lib().zns_scale_f32(s.data_ptr(), x0.data_ptr(), y0.data_ptr(), x0.numel(),
+                                      x1.data_ptr() if x1 is not None else None,
+                                      y1.data_ptr() if y1 is not None else None, x1.numel() if x1 is not None else 0,
+                                      stream_ptr(x0.device))
+    _lib.check(rc, "zns_scale_f32")
+    return (y0, y1) if x1 is not None else y0
 
 
 def head_fwd(nbr: int, B: int, T: int, h: torch.Tensor, w: Sequence[torch.Tensor], b: Sequence[torch.Tensor]):
@@ -296,11 +326,13 @@ def head_fwd(nbr: int, B: int, T: int, h: torch.Tensor, w: Sequence[torch.Tensor
 
 def head_bwd(nbr: int, B: int, T: int, h: torch.Tensor, emb: torch.Tensor, demb: torch.Tensor,
              w: Sequence[torch.Tensor], inv_keep: float, dw: Sequence[torch.Tensor], db: Sequence[torch.Tensor],
-             accumulate: bool, ws: torch.Tensor) -> torch.Tensor:
+             accumulate: bool, ws: torch.Tensor, demb1: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """demb1: branch 1's gradient rows when the two embeddings' gradients are separate tensors (demb: branch 0's)."""
     dz = torch.empty_like(h)
-    same_device(h, (emb, demb, *w, *dw, *db, ws), "head_bwd")
+    same_device(h, (emb, demb, *w, *dw, *db, ws, demb1), "head_bwd")
     with on_device(h):
-        rc = _lib.lib().zns_head_bwd_f32(nbr, B, T, 128, h.data_ptr(), emb.data_ptr(), demb.data_ptr(), _pp(w),
+        rc = _lib.lib().zns_head_bwd_f32(nbr, B, T, 128, h.data_ptr(), emb.data_ptr(), demb.data_ptr(),
+                                         demb1.data_ptr() if demb1 is not None else None, _pp(w),
                                          float(inv_keep), dz.data_ptr(), _pp(dw), _pp(db), int(bool(accumulate)),
                                          ws.data_ptr(), ws.numel(), stream_ptr(h.device))
     _lib.check(rc, "zns_head_bwd_f32")
@@ -334,8 +366,10 @@ class StackParams:
 
 
 def stack_forward(x: torch.Tensor, P: StackParams, B: int, drop_p: float, seed: int, save: bool,
-                  with_head: bool = True, ws_slot: int = 0):
+                  with_head: bool = True, ws_slot: int = 0, x1: Optional[torch.Tensor] = None):
     """x: [nbr*B, 1, 96, T] -> (emb [nbr*B, T] or None, acts [y1..y8], argmax {layer: u8}).
+    x1: branch 1's [B, 1, 96, T] when the two branches' inputs are separate tensors (x is then branch 0's): nothing is
+    concatenated, the first layer's kernels take both pointers.
     save=False is the inference form (nothing kept for a backward pass).  Packed weight operands are reused only inside
     a frozen_weights() block."""
     nbr = P.nbr
@@ -346,7 +380,8 @@ def stack_forward(x: torch.Tensor, P: StackParams, B: int, drop_p: float, seed: 
     argm: Dict[int, torch.Tensor] = {}
     cur = x
     for li in range(8):
-        y, am, spec = conv_fwd(li, nbr, B, T, cur, P.conv_w[li], P.conv_b[li], drop_p, seed, save, ws)
+        y, am, spec = conv_fwd(li, nbr, B, T, cur, P.conv_w[li], P.conv_b[li], drop_p, seed, save, ws,
+                               x1=x1 if li == 0 else None)
         if save:
             acts.append(y)
             if am is not None:
@@ -363,7 +398,8 @@ def stack_forward(x: torch.Tensor, P: StackParams, B: int, drop_p: float, seed: 
 def stack_backward(x: torch.Tensor, P: StackParams, B: int, acts: List[torch.Tensor], argm: Dict[int, torch.Tensor],
                    emb: Optional[torch.Tensor], demb: Optional[torch.Tensor], dh: Optional[torch.Tensor],
                    inv_keep: float, G: StackParams, accumulate: bool = False, conv_grads: bool = True,
-                   after_layer=None, ws_slot: int = 0) -> None:
+                   after_layer=None, ws_slot: int = 0, x1: Optional[torch.Tensor] = None,
+                   demb1: Optional[torch.Tensor] = None) -> None:
     """Writes parameter gradients into the tensors of G (same structure as P).
 
     demb: grad w.r.t. the embeddings (head fused) -- or dh: grad w.r.t. cv8's RAW output when the head
@@ -375,7 +411,7 @@ def stack_backward(x: torch.Tensor, P: StackParams, B: int, acts: List[torch.Ten
     with on_device(x):
         ws = workspace(conv_workspace_bytes(nbr, B, T), x.device, ws_slot)
     if demb is not None:
-        dz = head_bwd(nbr, B, T, acts[7], emb, demb, P.fc_w, inv_keep, G.fc_w, G.fc_b, accumulate, ws)
+        dz = head_bwd(nbr, B, T, acts[7], emb, demb, P.fc_w, inv_keep, G.fc_w, G.fc_b, accumulate, ws, demb1=demb1)
         if after_layer:
             after_layer("fc1")
     else:
@@ -390,6 +426,6 @@ def stack_backward(x: torch.Tensor, P: StackParams, B: int, acts: List[torch.Ten
             after_layer(LAYERS[li][0])
         prev_pool = LAYERS[li - 1][5]
         dz = conv_dgrad(li, nbr, B, T, dz, P.conv_w[li], xin, inv_keep, argm.get(li - 1), prev_pool, ws, dzs)
-    conv_wgrad(0, nbr, B, T, dz, x, G.conv_w[0], G.conv_b[0], accumulate, ws)
+    conv_wgrad(0, nbr, B, T, dz, x, G.conv_w[0], G.conv_b[0], accumulate, ws, x1=x1)
     if after_layer:
         after_layer("cv1")

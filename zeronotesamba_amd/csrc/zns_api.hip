@@ -45,7 +45,7 @@ using namespace zns;
 extern "C" {
 
 const char* zns_last_error(void) { return g_err; }
-int zns_version(void) { return 104; }   // 101: dzspec_out / dzspec, 102: stem mix + RMS gate, 103: NT-Xent workspace (any batch size), 104: packed-weight hand-off, staged xqt, multi-tensor Adam
+int zns_version(void) { return 105; }   // 105: separate branch inputs (x1 / demb1), zns_scale_f32, float64 NT-Xent tables   // 101: dzspec_out / dzspec, 102: stem mix + RMS gate, 103: NT-Xent workspace (any batch size), 104: packed-weight hand-off, staged xqt, multi-tensor Adam
 int zns_set_impl(int impl) {
     return g_impl.exchange(impl);
 }
@@ -150,7 +150,17 @@ int zns_conv2d_pack_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw
     return conv_family(a, !transposed) == 2 ? fft_pack(a, pw, transposed, dst, st) : mfma_pack(a, pw, transposed, dst, st);
 }
 
+// the per-branch input rows of a call: one stacked tensor, or (first layer only) the two branches' own tensors
+static int branch_inputs(const ConvArgs& a, const float* x, const float* x1, const char* who, Ptr2* out) {
+    ZNS_CHECK_ARG(x1 == nullptr || (a.nbr == 2 && a.cin == 1),
+                  "%s: separate branch inputs (x1) are taken by the first layer of a two-branch stack only", who);
+    out->p[0] = x;
+    out->p[1] = x1 ? x1 : x + (size_t)a.B * a.cin * a.H * a.T;
+    return ZNS_OK;
+}
+
 int zns_conv2d_fwd_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, int pool, const float* x,
+                       const float* x1,
                        const float* const* w, const float* const* bias, float* y, uint8_t* argmax, float drop_p,
                        uint32_t seed, int layer, float* xspec, const float* wpk, void* ws, size_t ws_bytes,
                        void* stream) {
@@ -161,8 +171,12 @@ int zns_conv2d_fwd_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw,
     Ptr2 pw{}, pb{};
     for (int i = 0; i < nbr; ++i) { pw.p[i] = w[i]; pb.p[i] = bias[i]; }
     hipStream_t st = (hipStream_t)stream;
-    if (g_impl == ZNS_IMPL_NAIVE) return naive_fwd(a, x, pw, pb, y, argmax, drop_p, seed, layer, st);
-    if (is_cv1(a) && pool == 1) return cv1_fwd(a, x, pw, pb, y, drop_p, seed, layer, st);
+    Ptr2 px{};
+    rc = branch_inputs(a, x, x1, "conv2d_fwd", &px);
+    if (rc) return rc;
+    if (g_impl == ZNS_IMPL_NAIVE) return naive_fwd(a, px, pw, pb, y, argmax, drop_p, seed, layer, st);
+    if (is_cv1(a) && pool == 1) return cv1_fwd(a, px, pw, pb, y, drop_p, seed, layer, st);
+    ZNS_CHECK_ARG(x1 == nullptr, "conv2d_fwd: separate branch inputs are taken by the cv1 kernels only");
     if (g_impl == ZNS_IMPL_AUTO && fft_supported(a))
         return fft_fwd(a, x, pw, pb, y, argmax, drop_p, seed, layer, xspec, wpk, ws, ws_bytes, st);
     if (mfma_supported(a)) return mfma_fwd(a, x, pw, pb, y, argmax, drop_p, seed, layer, wpk, ws, ws_bytes, st);
@@ -190,7 +204,7 @@ int zns_conv2d_dgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int k
 }
 
 int zns_conv2d_wgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, const float* dz,
-                         const float* x, float* const* dw, float* const* db, int accumulate, const float* xspec,
+                         const float* x, const float* x1, float* const* dw, float* const* db, int accumulate, const float* xspec,
                          float* dzspec_out, void* ws, size_t ws_bytes, void* stream) {
     ConvArgs a{nbr, B, T, cin, cout, kh, kw, H, 1};
     int rc = check_conv(a, "conv2d_wgrad");
@@ -198,12 +212,16 @@ int zns_conv2d_wgrad_f32(int nbr, int B, int T, int cin, int cout, int kh, int k
     MPtr2 pdw{}, pdb{};
     for (int i = 0; i < nbr; ++i) { pdw.p[i] = dw[i]; pdb.p[i] = db[i]; }
     hipStream_t st = (hipStream_t)stream;
+    Ptr2 px{};
+    rc = branch_inputs(a, x, x1, "conv2d_wgrad", &px);
+    if (rc) return rc;
     if (g_impl == ZNS_IMPL_NAIVE) {
-        rc = naive_wgrad(a, dz, x, pdw, accumulate, st);
+        rc = naive_wgrad(a, dz, px, pdw, accumulate, st);
         if (rc) return rc;
         return channel_sum(nbr, B, cout, (long long)H * T, dz, pdb, accumulate, st);
     }
-    if (is_cv1(a)) return cv1_wgrad(a, dz, x, pdw, pdb, accumulate, ws, ws_bytes, st);
+    if (is_cv1(a)) return cv1_wgrad(a, dz, px, pdw, pdb, accumulate, ws, ws_bytes, st);
+    ZNS_CHECK_ARG(x1 == nullptr, "conv2d_wgrad: separate branch inputs are taken by the cv1 kernels only");
     if (g_impl == ZNS_IMPL_AUTO && fft_wgrad_supported(a))
         return fft_wgrad(a, dz, x, pdw, pdb, accumulate, xspec, dzspec_out, ws, ws_bytes, st);
     if (mfma_supported(a)) {

@@ -760,8 +760,11 @@ using FF4w = ConvCfg<128, 128, 1, 9, 1, 1, 1, 5, 4, 1, 1, 4, 1, 1, FDIL128>;
 using FF4wa = ConvCfg<128, 128, 1, 9, 1, 1, 1, 3, 4, 1, 1, 4, 1, 1, FDIL128>;
 using FD4w = FF4w;
 using FD4wa = FF4wa;
-// cv3 backward-data: two channel tiles x five column tiles = two waves of (1 x 5)
-using FD3w = ConvCfg<128, 64, 1, 5, 1, 1, 1, 5, 2, 1, 1, 8, 1, 1, FDIL128>;
+// cv3 backward-data (two channel tiles x five column tiles): four waves of (1 x 3) over 192 columns, the sixth column tile
+// dead (conv_core's live-tile K loop skips it).  Measured per step at T = 512, same box: 22.73 ms against 22.81 for two waves
+// of (1 x 5), 22.79 for one wave of (2 x 5), 22.84 for two waves of (2 x 3); cv3 forward as two waves of (2 x 5): 22.88; cv4
+// as two waves of (2 x 5) (352 registers, one wave per SIMD): 23.08.
+using FD3w = ConvCfg<128, 64, 1, 5, 1, 1, 1, 3, 2, 1, 2, 8, 1, 1, FDIL128>;
 using FD3wa = ConvCfg<128, 64, 1, 5, 1, 1, 1, 3, 2, 1, 1, 8, 1, 1, FDIL128>;
 //                 CIN COUT KH KW(taps) H  MT NS WMW WQ R DILMAX WCI
 using FW2 = WgCfg<64, 64, 1, 7, 1, 1, 7, 2, 1, 1, FDILW, 2, 32>;

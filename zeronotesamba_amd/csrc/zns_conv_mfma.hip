@@ -240,25 +240,27 @@ __global__ void __launch_bounds__(256) conv_split_finish_kernel(const float* __r
     }
 }
 
-static int ksplit_mode() { return tuning(ZNS_TUNE_KSPLIT); }   // -1: automatic; 0: off; 2 / 4 / 8: forced split (tests)
-// How many ways the K loop of a cv7 / cv8 launch is split (1 = the unsplit kernels): all eight, or not at all -- and the
-// choice follows T alone, never the batch: the summation order of a clip's activations must not depend on the batch it is
-// in (tests/test_gpu_fullsize.py: a batch of 80 equals its chunks of 16 bit for bit).  Rows whose 64-column tiles come in
-// multiples of eight (T = 512: 8 per clip, 256 for the reference's batch of 16 pairs = one per CU) stay unsplit: measured
-// per step, unsplit / 2 / 4 / 8 ways, T = 512: 23.23 / 23.12 / 23.25 / 23.23 ms (the split kernels' 5-20 % are what the finish
-// launches cost: cv7 backward-data writes 134 MB of unpooled rows in any case); T = 313 (5 tiles per clip, 160 per batch):
-// 16.90 / 16.77 / 16.74 / 16.73 ms; the batch-of-one fine-tune step (T = 1876, 30 tiles): 7.24 / 7.04 / 7.02 / 6.97 ms.
-// The split sums are also the more accurate ones (eight chains of an eighth of the terms: 3.5e-7 against 9.6e-7 rms of a
-// float64 convolution) -- which moves them AWAY from the float32 CPU oracle, whose own chain errs like the unsplit kernel's:
-// at T = 512 the full-size oracle test's worst gradient read 1.01e-4 of its norm with the split against 6.2e-5 without.
-// zns_test_set_tuning(ZNS_TUNE_KSPLIT, 0 / 2 / 4 / 8) overrides (tests, tuning).
+static int ksplit_mode() { return tuning(ZNS_TUNE_KSPLIT); }   // -1: the product rule; 0: off; 2 / 4 / 8: forced split (tests)
+// How many ways the K loop of a cv7 / cv8 launch is split (1 = the unsplit kernels): all eight, at every T -- never a
+// function of the batch: the summation order of a clip's activations must not depend on the batch it is in
+// (tests/test_gpu_fullsize.py: a batch of 80 equals its chunks of 16 bit for bit).  Measured per step, unsplit / 2 / 4 / 8
+// ways: T = 512 (8 tiles per clip, 256 per batch of 16 pairs = one per CU unsplit): 23.23 / 23.12 / 23.25 / 23.23 ms (what
+// the split kernels gain there, the finish launches cost: cv7 backward-data writes 134 MB of unpooled rows in any case);
+// T = 313 (5 tiles per clip, 160 per batch): 16.90 / 16.77 / 16.74 / 16.73 ms; the batch-of-one fine-tune step (T = 1876, 30
+// tiles): 7.24 / 7.04 / 7.02 / 6.97 ms.  The split sums are also the more accurate ones -- eight chains of an eighth of the
+// terms, added pairwise: 3.5e-7 against 9.6e-7 rms of a float64 convolution, where torch's own CPU convolution sits at
+// 5e-7 .. 9e-7 (tools/diag_win_accuracy.py) -- so round 5 made them the rule at T = 512 too.  (Round 4 kept T = 512 unsplit
+// because the full-size oracle test's worst gradient read 1.01e-4 with the split against 6.2e-5 without: that number was
+// the NT-Xent kernels' float32 tables reacting to ANY change of the embeddings' last bits, see zns_small.hip; with
+// float64 tables the same test reads 4e-5 unsplit.)
+// zns_test_set_tuning(ZNS_TUNE_KSPLIT, 0 / 2 / 4 / 8) overrides (tests compare the unsplit kernels).
 template <class C>
 static int ksplit_ways(const ConvArgs& a) {
     if (a.H != 1) return 1;
     const int m = ksplit_mode();
     if (m == 0) return 1;
     if (m == 2 || m == 4 || m == 8) return m;
-    return ceil_div(a.T, C::WB) % 8 == 0 ? 1 : KSPLIT_PARTS;
+    return KSPLIT_PARTS;
 }
 template <class C>
 static size_t ksplit_slab_bytes(const ConvArgs& a) {

@@ -20,7 +20,7 @@ constexpr int C1_STEPS = (CV1_KH * CV1_KW + 1) / 2;     // 17 k-steps of 2 taps 
 // registers for the whole kernel; B is one LDS read per k-step at a per-lane tap offset computed once.  Epilogue on the
 // accumulators: bias, ReLU, dropout hash of the output's linear index, 4-byte buffer stores (32 consecutive pixels of one
 // channel per half wave = 128-byte runs; the channel goes into the scalar offset, out-of-row lanes out of range).
-__global__ void __launch_bounds__(256) cv1_fwd_kernel(int B, int T, int H, const float* __restrict__ x, Ptr2 w,
+__global__ void __launch_bounds__(256) cv1_fwd_kernel(int B, int T, int H, Ptr2 xb, Ptr2 w,
                                                       Ptr2 bias, float* __restrict__ y, uint32_t thresh,
                                                       float inv_keep, uint32_t seed, int layer, int tblocks) {
     __shared__ float sx[CV1_KH * C1_RS];
@@ -31,10 +31,11 @@ __global__ void __launch_bounds__(256) cv1_fwd_kernel(int B, int T, int H, const
     const int n = bid / H;
     const int br = n / B, b = n % B;
     const int t_blk = tb * C1_TB;
+    const float* __restrict__ x = xb.p[br] + (size_t)b * H * T;      // this sample's rows (the branches' inputs may be separate tensors)
     for (int i = threadIdx.x; i < CV1_KH * (C1_TB + CV1_KW - 1); i += 256) {
         const int r = i / (C1_TB + CV1_KW - 1), c = i - r * (C1_TB + CV1_KW - 1);
         const int hh = h + r - 1, tt = t_blk + c - CV1_KW / 2;
-        sx[r * C1_RS + c] = (hh >= 0 && hh < H && tt >= 0 && tt < T) ? x[((size_t)n * H + hh) * T + tt] : 0.f;
+        sx[r * C1_RS + c] = (hh >= 0 && hh < H && tt >= 0 && tt < T) ? x[(size_t)hh * T + tt] : 0.f;
     }
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int half = lane >> 5, px = lane & 31;
@@ -104,13 +105,14 @@ __global__ void __launch_bounds__(256) cv1_fwd_kernel(int B, int T, int H, const
 // cv1_wgrad_reduce adds the B*H blocks in a fixed order.
 constexpr int CW_TC = 128, CW_XS = CW_TC + 16, CW_K1 = CV1_KH * CV1_KW + 1;
 
-__global__ void __launch_bounds__(256) cv1_wgrad_kernel(int T, int H, const float* __restrict__ dz,
-                                                        const float* __restrict__ x, float* __restrict__ part) {
+__global__ void __launch_bounds__(256) cv1_wgrad_kernel(int B, int T, int H, const float* __restrict__ dz,
+                                                        Ptr2 xb, float* __restrict__ part) {
     // the dZ tile of the K loop and, after it, the four waves' partial sums share one buffer
     __shared__ float sbuf[4 * CW_K1 * CV1_CO > CV1_CO * (CW_TC + 1) ? 4 * CW_K1 * CV1_CO : CV1_CO * (CW_TC + 1)];
     __shared__ __attribute__((aligned(16))) float sx[CV1_KH * CW_XS];
     float* const sdz = sbuf;
     const int h = blockIdx.x % H, n = blockIdx.x / H;
+    const float* __restrict__ x = xb.p[n / B] + (size_t)(n % B) * H * T;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int half = lane >> 5, tap = lane & 31;
@@ -141,7 +143,7 @@ __global__ void __launch_bounds__(256) cv1_wgrad_kernel(int T, int H, const floa
             const int i = threadIdx.x + j * 256;
             const int r = i / CW_XS, c = i % CW_XS;
             const int hh = h + r - 1, tt = t0 + c - 5;
-            vx[j] = (i < CV1_KH * CW_XS && hh >= 0 && hh < H && tt >= 0 && tt < T) ? x[((size_t)n * H + hh) * T + tt] : 0.f;
+            vx[j] = (i < CV1_KH * CW_XS && hh >= 0 && hh < H && tt >= 0 && tt < T) ? x[(size_t)hh * T + tt] : 0.f;
         }
     };
     fetch(0);
@@ -220,7 +222,7 @@ size_t cv1_workspace_bytes(const ConvArgs& a) {
     return (size_t)a.nbr * a.B * CV1_CO * a.H * (CV1_KH * CV1_KW + 1) * sizeof(float);
 }
 
-int cv1_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, float drop_p, uint32_t seed, int layer,
+int cv1_fwd(const ConvArgs& a, Ptr2 x, Ptr2 w, Ptr2 bias, float* y, float drop_p, uint32_t seed, int layer,
             hipStream_t st) {
     // the kernel's 32-bit channel offsets (stores and the dropout index), and its masked lanes: a lane past the row's end
     // carries voffset 0x80000000 and relies on the buffer's range check (voffset + instruction offset >= num_records; the
@@ -239,14 +241,14 @@ int cv1_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, floa
     return ZNS_OK;
 }
 
-int cv1_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, MPtr2 db, int accumulate, void* ws,
+int cv1_wgrad(const ConvArgs& a, const float* dz, Ptr2 x, MPtr2 dw, MPtr2 db, int accumulate, void* ws,
               size_t ws_bytes, hipStream_t st) {
     if (ws_bytes < cv1_workspace_bytes(a)) {
         set_error("cv1_wgrad: workspace %zu < %zu", ws_bytes, cv1_workspace_bytes(a));
         return ZNS_ERR_WORKSPACE;
     }
     float* part = (float*)ws;
-    hipLaunchKernelGGL(cv1_wgrad_kernel, dim3(a.nbr * a.B * a.H), dim3(256), 0, st, a.T, a.H, dz, x, part);
+    hipLaunchKernelGGL(cv1_wgrad_kernel, dim3(a.nbr * a.B * a.H), dim3(256), 0, st, a.B, a.T, a.H, dz, x, part);
     ZNS_LAUNCH_CHECK();
     hipLaunchKernelGGL(cv1_wgrad_reduce, dim3(a.nbr * (CW_K1 * CV1_CO / 64)), dim3(1024), 0, st, a.B, a.H, part, dw, db,
                        accumulate, a.nbr);

@@ -25,11 +25,12 @@ struct ConvArgs {
 };
 
 // zns_naive.hip
-int naive_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, uint8_t* argmax, float drop_p,
+// x: per-branch input rows (x.p[br] = the branch's B samples; one stacked tensor is {x, x + B * cin * H * T})
+int naive_fwd(const ConvArgs& a, Ptr2 x, Ptr2 w, Ptr2 bias, float* y, uint8_t* argmax, float drop_p,
               uint32_t seed, int layer, hipStream_t st);
 int naive_dgrad(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, const float* x, float inv_keep,
                 const uint8_t* prev_argmax, int prev_pool, hipStream_t st);
-int naive_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, int accumulate, hipStream_t st);
+int naive_wgrad(const ConvArgs& a, const float* dz, Ptr2 x, MPtr2 dw, int accumulate, hipStream_t st);
 int channel_sum(int nbr, int B, int C, long long HT, const float* dz, MPtr2 db, int accumulate, hipStream_t st);
 
 // zns_conv_mfma.hip -- return ZNS_ERR_ARG (without setting an error) when the shape has no instance
@@ -64,9 +65,9 @@ int fft_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, MPtr
               const float* xspec, float* dzspec_out, void* ws, size_t ws_bytes, hipStream_t st);   // also writes the bias gradient
 
 // zns_cv1.hip -- direct (HBM-bound) kernels for the cin==1 first layer
-int cv1_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, float drop_p, uint32_t seed,
+int cv1_fwd(const ConvArgs& a, Ptr2 x, Ptr2 w, Ptr2 bias, float* y, float drop_p, uint32_t seed,
             int layer, hipStream_t st);
-int cv1_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, MPtr2 db, int accumulate, void* ws,
+int cv1_wgrad(const ConvArgs& a, const float* dz, Ptr2 x, MPtr2 dw, MPtr2 db, int accumulate, void* ws,
               size_t ws_bytes, hipStream_t st);
 size_t cv1_workspace_bytes(const ConvArgs& a);
 

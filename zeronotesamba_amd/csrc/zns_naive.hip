@@ -7,7 +7,7 @@
 namespace zns {
 
 __global__ void naive_conv_fwd(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H, int pool,
-                               const float* __restrict__ x, Ptr2 w, Ptr2 bias, float* __restrict__ y,
+                               Ptr2 x, Ptr2 w, Ptr2 bias, float* __restrict__ y,
                                uint8_t* __restrict__ argmax, uint32_t thresh, float inv_keep, uint32_t seed,
                                int layer) {
     const int Hp = H / pool;
@@ -30,7 +30,7 @@ __global__ void naive_conv_fwd(int nbr, int B, int T, int cin, int cout, int kh,
             const int h = hp * pool + a;
             float acc = 0.f;
             for (int ci = 0; ci < cin; ++ci) {
-                const float* xp = x + ((size_t)n * cin + ci) * H * T;
+                const float* xp = x.p[br] + ((size_t)(n - br * B) * cin + ci) * H * T;
                 const float* wp = wb + (size_t)ci * kh * kw;
                 for (int r = 0; r < kh; ++r) {
                     const int hh = h + r - ph;
@@ -101,7 +101,7 @@ __global__ void naive_conv_dgrad(int nbr, int B, int T, int cin, int cout, int k
 
 // one wave per weight element
 __global__ void naive_conv_wgrad(int nbr, int B, int T, int cin, int cout, int kh, int kw, int H,
-                                 const float* __restrict__ dz, const float* __restrict__ x, MPtr2 dw,
+                                 const float* __restrict__ dz, Ptr2 x, MPtr2 dw,
                                  int accumulate) {
     const long long per_branch = (long long)cout * cin * kh * kw;
     const long long o = blockIdx.x;
@@ -118,7 +118,7 @@ __global__ void naive_conv_wgrad(int nbr, int B, int T, int cin, int cout, int k
     for (int b = 0; b < B; ++b) {
         const int n = br * B + b;
         const float* zp = dz + ((size_t)n * cout + co) * H * T;
-        const float* xp = x + ((size_t)n * cin + ci) * H * T;
+        const float* xp = x.p[br] + ((size_t)b * cin + ci) * H * T;
         for (int h = 0; h < H; ++h) {
             const int hh = h + r - ph;
             if (hh < 0 || hh >= H) continue;
@@ -159,7 +159,7 @@ __global__ void channel_sum_kernel(int B, int C, long long HT, const float* __re
     }
 }
 
-int naive_fwd(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float* y, uint8_t* argmax, float drop_p,
+int naive_fwd(const ConvArgs& a, Ptr2 x, Ptr2 w, Ptr2 bias, float* y, uint8_t* argmax, float drop_p,
               uint32_t seed, int layer, hipStream_t st) {
     const long long total = (long long)a.nbr * a.B * a.cout * (a.H / a.pool) * a.T;
     const int blocks = (int)((total + 255) / 256 > 65536 * 4 ? 65536 * 4 : (total + 255) / 256);
@@ -181,7 +181,7 @@ int naive_dgrad(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, const flo
     return ZNS_OK;
 }
 
-int naive_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, int accumulate, hipStream_t st) {
+int naive_wgrad(const ConvArgs& a, const float* dz, Ptr2 x, MPtr2 dw, int accumulate, hipStream_t st) {
     const long long total = (long long)a.nbr * a.cout * a.cin * a.kh * a.kw;
     hipLaunchKernelGGL(naive_conv_wgrad, dim3((unsigned)total), dim3(64), 0, st, a.nbr, a.B, a.T, a.cin, a.cout,
                        a.kh, a.kw, a.H, dz, x, dw, accumulate);

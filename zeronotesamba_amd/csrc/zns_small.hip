@@ -55,17 +55,18 @@ __global__ void __launch_bounds__(256) head_fwd_kernel(int B, int T, int C, cons
 
 // one block per (n, c): writes dz row, partial dw; c==0 block also writes the partial db
 __global__ void head_bwd_kernel(int B, int T, int C, const float* __restrict__ h, const float* __restrict__ emb,
-                                const float* __restrict__ demb, Ptr2 w, float inv_keep, float* __restrict__ dz,
+                                Ptr2 dembb, Ptr2 w, float inv_keep, float* __restrict__ dz,
                                 float* __restrict__ part_w, float* __restrict__ part_b) {
     __shared__ float red[16];
     const int c = blockIdx.x % C, n = blockIdx.x / C, br = n / B;
     const float wc = w.p[br][c];
+    const float* __restrict__ demb = dembb.p[br] + (size_t)(n - br * B) * T;     // (the branches' gradients may be separate tensors)
     const float* hp = h + ((size_t)n * C + c) * T;
     float* zp = dz + ((size_t)n * C + c) * T;
     float sw = 0.f, sb = 0.f;
     for (int t = threadIdx.x; t < T; t += blockDim.x) {
         const float e = emb[(size_t)n * T + t];
-        const float dpre = demb[(size_t)n * T + t] * e * (1.0f - e);
+        const float dpre = demb[t] * e * (1.0f - e);
         const float hv = hp[t];
         sw = fmaf(dpre, hv, sw);
         sb += dpre;
@@ -123,7 +124,7 @@ __global__ void down_bwd_kernel(const float* __restrict__ a, const float* __rest
 
 // ------------------------------------------------------------------ NT-Xent (loss_functions.py:24-55)
 // Any number of rows R (the reference's batch_size comes from config.yaml), three short launches over a caller
-// workspace  S[R][R] | na2[R] | np2[R] | Ga[R][R] | Gp[R][R] | s1[R] | s2[R]  (floats):
+// workspace  S[R][R] | na2[R] | np2[R] | Ga[R][R] | Gp[R][R] | s1[R] | s2[R]  (float64, see below):
 //   1. ntx_dots:    one wave per dot product: S[i][j] = a_i . p_j, na2[i] = a_i . a_i, np2[j] = p_j . p_j
 //   2. ntx_softmax: one thread per anchor row: C = S / (|a_i| |p_j|) (norms clamped at eps = 1e-8 as
 //                   nn.CosineSimilarity), L_i = logsumexp_j(C_ij / tau) - C_ii / tau, the three statistics (summed in
@@ -132,15 +133,30 @@ __global__ void down_bwd_kernel(const float* __restrict__ a, const float* __rest
 //   3. ntx_grad:    ga_i = (sum_j Ga[i][j] p_j  -  a_i s1_i / |a_i|) / |a_i|      (d cos / d a through the normalisation;
 //                   gp_j = (sum_i Gp[j][i] a_i  -  p_j s2_j / |p_j|) / |p_j|       gah_i . ah_i = sum_j G_ij C_ij exactly)
 // The 16 x 16 x 512 case of the benchmark took 0.14 ms as one serial 1024-thread block; it is now ~3 launch latencies.
+__device__ inline double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// The R x R tables (dot products, cosines, softmax weights, the gradient operators) are FLOAT64, and so is the final
+// combination of the gradient kernel; only the result is rounded to float32.  Why: with near-collinear embeddings (a freshly
+// initialised model: every cosine 0.99, loss = ln(batch) to four digits) the gradient is what is left after the common
+// direction cancels, and every rounded SCALAR of the chain -- a cosine, a softmax weight, s1 -- multiplies a whole embedding
+// vector: its rounding error is coherent along the embedding, and fc1's weight gradient (a sum over frames against
+// non-negative activations, condition number ~300 here) amplifies exactly that component.  Measured at B = 16, D = 512:
+// one float32 ulp (6e-8) in s1 moves fc1.weight's gradient by 5e-5 of its norm; the float32 tables put the full-size step's
+// worst gradient at 6e-5 .. 3.7e-4 of its norm from the CPU oracle depending on how the roundings fell (torch's autograd
+// rounds per ELEMENT, incoherently: 7e-6).  The tables are 3 R^2 + 4 R numbers; float64 costs nothing measurable.
 __global__ void __launch_bounds__(256) ntx_dots_kernel(const float* __restrict__ a, const float* __restrict__ p, int R,
-                                                       int D, float* __restrict__ S, float* __restrict__ na2,
-                                                       float* __restrict__ np2) {
+                                                       int D, double* __restrict__ S, double* __restrict__ na2,
+                                                       double* __restrict__ np2) {
     const int lane = threadIdx.x & 63;
     const long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long nq = (long long)R * R + 2 * R;
     if (q >= nq) return;
     const float *u, *v;
-    float* dst;
+    double* dst;
     if (q < (long long)R * R) {
         u = a + (size_t)(q / R) * D;
         v = p + (size_t)(q % R) * D;
@@ -152,44 +168,45 @@ __global__ void __launch_bounds__(256) ntx_dots_kernel(const float* __restrict__
         u = v = p + (size_t)(q - (long long)R * R - R) * D;
         dst = np2 + (q - (long long)R * R - R);
     }
-    float s = 0.f;
-    for (int d = lane; d < D; d += 64) s = fmaf(u[d], v[d], s);
-    s = wave_sum(s);
+    double s = 0.0;
+    for (int d = lane; d < D; d += 64) s = fma((double)u[d], (double)v[d], s);
+    s = wave_sum_f64(s);
     if (lane == 0) *dst = s;
 }
 
-__global__ void __launch_bounds__(1024) ntx_softmax_kernel(int R, int batch_len, float tau, float grad_scale,
-                                                           const float* __restrict__ S, const float* __restrict__ na2,
-                                                           const float* __restrict__ np2, float* __restrict__ Ga,
-                                                           float* __restrict__ Gp, float* __restrict__ s1,
-                                                           float* __restrict__ s2, float* __restrict__ out3, int want_grad) {
+__global__ void __launch_bounds__(1024) ntx_softmax_kernel(int R, int batch_len, float tau_f, float grad_scale,
+                                                           const double* __restrict__ S, const double* __restrict__ na2,
+                                                           const double* __restrict__ np2, double* __restrict__ Ga,
+                                                           double* __restrict__ Gp, double* __restrict__ s1,
+                                                           double* __restrict__ s2, float* __restrict__ out3,
+                                                           float* __restrict__ loss_out, int want_grad) {
     __shared__ double red[3][16];
-    const float eps = 1e-8f;
+    const double eps = 1e-8, tau = (double)tau_f;
     double l = 0, ps = 0, ns = 0;
     for (int i = threadIdx.x; i < R; i += 1024) {
-        const float nai = fmaxf(sqrtf(na2[i]), eps);
-        const float* Si = S + (size_t)i * R;
-        float m = -INFINITY;
-        for (int j = 0; j < R; ++j) m = fmaxf(m, Si[j] / (nai * fmaxf(sqrtf(np2[j]), eps)) / tau);
-        float z = 0.f, rs = 0.f;
+        const double nai = fmax(sqrt(na2[i]), eps);
+        const double* Si = S + (size_t)i * R;
+        double m = -INFINITY;
+        for (int j = 0; j < R; ++j) m = fmax(m, Si[j] / (nai * fmax(sqrt(np2[j]), eps)) / tau);
+        double z = 0.0, rs = 0.0;
         for (int j = 0; j < R; ++j) {
-            const float c = Si[j] / (nai * fmaxf(sqrtf(np2[j]), eps));
-            z += expf(c / tau - m);
+            const double c = Si[j] / (nai * fmax(sqrt(np2[j]), eps));
+            z += exp(c / tau - m);
             rs += c;
         }
-        const float cii = Si[i] / (nai * fmaxf(sqrtf(np2[i]), eps));
-        l += (double)((m + logf(z)) - cii / tau);
-        ps += (double)cii;
-        ns += (double)((rs - cii) / (float)(batch_len - 1));
+        const double cii = Si[i] / (nai * fmax(sqrt(np2[i]), eps));
+        l += (m + log(z)) - cii / tau;
+        ps += cii;
+        ns += (rs - cii) / (double)(batch_len - 1);
         if (want_grad) {
-            float acc = 0.f;
+            double acc = 0.0;
             for (int j = 0; j < R; ++j) {
-                const float npj = fmaxf(sqrtf(np2[j]), eps);
-                const float c = Si[j] / (nai * npj);
-                const float g = (expf(c / tau - m) / z - (i == j ? 1.f : 0.f)) * grad_scale / (tau * (float)batch_len);
+                const double npj = fmax(sqrt(np2[j]), eps);
+                const double c = Si[j] / (nai * npj);
+                const double g = (exp(c / tau - m) / z - (i == j ? 1.0 : 0.0)) * (double)grad_scale / (tau * (double)batch_len);
                 Ga[(size_t)i * R + j] = g / npj;
                 Gp[(size_t)j * R + i] = g / nai;
-                acc = fmaf(g, c, acc);
+                acc = fma(g, c, acc);
             }
             s1[i] = acc;
         }
@@ -209,17 +226,18 @@ __global__ void __launch_bounds__(1024) ntx_softmax_kernel(int R, int batch_len,
             double t = 0;
             for (int w = 0; w < 16; ++w) t += red[k][w];
             out3[k] = (float)(t / batch_len);
+            if (k == 0 && loss_out) *loss_out = (float)(t / batch_len);
         }
     }
     if (!want_grad) return;
     // s2_j = sum_i G_ij C_ij = sum_i Gp[j][i] |a_i| * C_ij : one thread per column, after every row has been written
     __syncthreads();
     for (int j = threadIdx.x; j < R; j += 1024) {
-        const float npj = fmaxf(sqrtf(np2[j]), eps);
-        float acc = 0.f;
+        const double npj = fmax(sqrt(np2[j]), eps);
+        double acc = 0.0;
         for (int i = 0; i < R; ++i) {
-            const float nai = fmaxf(sqrtf(na2[i]), eps);
-            acc = fmaf(Gp[(size_t)j * R + i] * nai, S[(size_t)i * R + j] / (nai * npj), acc);
+            const double nai = fmax(sqrt(na2[i]), eps);
+            acc = fma(Gp[(size_t)j * R + i] * nai, S[(size_t)i * R + j] / (nai * npj), acc);
         }
         s2[j] = acc;
     }
@@ -227,21 +245,33 @@ __global__ void __launch_bounds__(1024) ntx_softmax_kernel(int R, int batch_len,
 
 // grid (ceil(D / 256), R, 2): side 0 -> ga row i, side 1 -> gp row i
 __global__ void __launch_bounds__(256) ntx_grad_kernel(const float* __restrict__ a, const float* __restrict__ p, int R,
-                                                       int D, const float* __restrict__ na2, const float* __restrict__ np2,
-                                                       const float* __restrict__ Ga, const float* __restrict__ Gp,
-                                                       const float* __restrict__ s1, const float* __restrict__ s2,
+                                                       int D, const double* __restrict__ na2, const double* __restrict__ np2,
+                                                       const double* __restrict__ Ga, const double* __restrict__ Gp,
+                                                       const double* __restrict__ s1, const double* __restrict__ s2,
                                                        float* __restrict__ ga, float* __restrict__ gp) {
     const int d = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y, side = blockIdx.z;
     float* out = side ? gp : ga;
     if (d >= D || out == nullptr) return;
-    const float* G = (side ? Gp : Ga) + (size_t)i * R;      // wave-uniform row of the operator
+    const double* G = (side ? Gp : Ga) + (size_t)i * R;      // wave-uniform row of the operator
     const float* other = side ? a : p;
     const float* self = side ? p : a;
-    const float nrm = fmaxf(sqrtf((side ? np2 : na2)[i]), 1e-8f);
-    float acc = 0.f;
-    for (int j = 0; j < R; ++j) acc = fmaf(G[j], other[(size_t)j * D + d], acc);
-    const float sdot = (side ? s2 : s1)[i];
-    out[(size_t)i * D + d] = (acc - (self[(size_t)i * D + d] / nrm) * sdot) / nrm;
+    const double nrm = fmax(sqrt((side ? np2 : na2)[i]), 1e-8);
+    double acc = 0.0;
+    for (int j = 0; j < R; ++j) acc = fma(G[j], (double)other[(size_t)j * D + d], acc);
+    const double sdot = (side ? s2 : s1)[i];
+    out[(size_t)i * D + d] = (float)((acc - ((double)self[(size_t)i * D + d] / nrm) * sdot) / nrm);
+}
+
+// y = x * scale[0], scale a device scalar: the chain-rule factor autograd hands a loss node's backward (dloss), applied
+// without reading it back to the host and without an ATen launch; up to two arrays per launch (NT-Xent: ga and gp)
+__global__ void scale_kernel(const float* __restrict__ scale, const float* __restrict__ x0, float* __restrict__ y0,
+                             size_t n0, const float* __restrict__ x1, float* __restrict__ y1, size_t n1) {
+    const float s = scale[0];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n0 + n1; i += stride) {
+        if (i < n0) y0[i] = x0[i] * s;
+        else y1[i - n0] = x1[i - n0] * s;
+    }
 }
 
 // ------------------------------------------------------------------ BCELoss (loader.py:16)
@@ -444,9 +474,13 @@ int zns_head_fwd_f32(int nbr, int B, int T, int C, const float* h, const float* 
 }
 
 int zns_head_bwd_f32(int nbr, int B, int T, int C, const float* h, const float* emb, const float* demb,
-                     const float* const* w, float inv_keep, float* dz, float* const* dw, float* const* db,
+                     const float* demb1, const float* const* w, float inv_keep, float* dz, float* const* dw, float* const* db,
                      int accumulate, void* ws, size_t ws_bytes, void* stream) {
     ZNS_CHECK_ARG(nbr >= 1 && nbr <= 2 && B > 0 && T > 0 && C > 0, "head_bwd: bad shape");
+    ZNS_CHECK_ARG(demb1 == nullptr || nbr == 2, "head_bwd: demb1 (branch 1's own gradient tensor) needs nbr = 2");
+    Ptr2 pd{};
+    pd.p[0] = demb;
+    pd.p[1] = demb1 ? demb1 : demb + (size_t)B * T;
     const size_t need = ((size_t)nbr * B * C + (size_t)nbr * B) * sizeof(float);
     if (ws_bytes < need) { set_error("head_bwd: workspace %zu < %zu", ws_bytes, need); return ZNS_ERR_WORKSPACE; }
     Ptr2 pw{}; MPtr2 pdw{}, pdb{};
@@ -454,7 +488,7 @@ int zns_head_bwd_f32(int nbr, int B, int T, int C, const float* h, const float* 
     float* part_w = (float*)ws;
     float* part_b = part_w + (size_t)nbr * B * C;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(nbr * B * C), dim3(128), 0, st, B, T, C, h, emb, demb, pw, inv_keep, dz,
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(nbr * B * C), dim3(128), 0, st, B, T, C, h, emb, pd, pw, inv_keep, dz,
                        part_w, part_b);
     ZNS_LAUNCH_CHECK();
     hipLaunchKernelGGL(head_bwd_reduce, dim3((nbr * (C + 1) + 127) / 128), dim3(128), 0, st, B, C, part_w, part_b,
@@ -484,13 +518,13 @@ int zns_down_bwd_f32(const float* a, const float* p, const float* dout, size_t n
 
 size_t zns_ntxent_workspace_bytes(int rows) {
     if (rows < 1) return 256;
-    return (((size_t)3 * rows * rows + 4 * (size_t)rows) * sizeof(float) + 255) & ~(size_t)255;
+    return (((size_t)3 * rows * rows + 4 * (size_t)rows) * sizeof(double) + 255) & ~(size_t)255;
 }
 
-int zns_ntxent_f32(const float* a, const float* p, int rows, int D, int batch_len, float tau, float* out3, float* ga,
-                   float* gp, float grad_scale, void* ws, size_t ws_bytes, void* stream) {
+int zns_ntxent_f32(const float* a, const float* p, int rows, int D, int batch_len, float tau, float* out3, float* loss_out,
+                   float* ga, float* gp, float grad_scale, void* ws, size_t ws_bytes, void* stream) {
     // the log-softmax pass is ONE workgroup (a thread per row, O(rows^2)): sized for batch sizes the reference can hold
-    // (config.yaml batch_size 16; a 2048-row batch is already 3 x 16 MB of scratch), refused beyond
+    // (config.yaml batch_size 16; a 2048-row batch is already 3 x 32 MB of scratch), refused beyond
     ZNS_CHECK_ARG(rows >= 1 && rows <= 2048, "ntxent: rows=%d (supported: 1..2048)", rows);
     ZNS_CHECK_ARG(D >= 1 && batch_len >= 2 && rows <= batch_len, "ntxent: bad D/batch_len");
     if (ws == nullptr || ws_bytes < zns_ntxent_workspace_bytes(rows)) {
@@ -499,26 +533,37 @@ int zns_ntxent_f32(const float* a, const float* p, int rows, int D, int batch_le
     }
     hipStream_t st = (hipStream_t)stream;
     const size_t R = (size_t)rows;
-    float* S = (float*)ws;
-    float* na2 = S + R * R;
-    float* np2 = na2 + R;
-    float* Ga = np2 + R;
-    float* Gp = Ga + R * R;
-    float* s1 = Gp + R * R;
-    float* s2 = s1 + R;
+    double* S = (double*)ws;        // float64 tables: see ntx_dots_kernel
+    double* na2 = S + R * R;
+    double* np2 = na2 + R;
+    double* Ga = np2 + R;
+    double* Gp = Ga + R * R;
+    double* s1 = Gp + R * R;
+    double* s2 = s1 + R;
     const long long nq = (long long)R * R + 2 * R;
     hipLaunchKernelGGL(ntx_dots_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, a, p, rows, D, S, na2, np2);
     ZNS_LAUNCH_CHECK();
     const int want_grad = (ga != nullptr || gp != nullptr) ? 1 : 0;
-    hipLaunchKernelGGL(ntx_softmax_kernel, dim3(1), dim3(1024), 0, st, rows, batch_len, tau, grad_scale, (const float*)S,
-                       (const float*)na2, (const float*)np2, Ga, Gp, s1, s2, out3, want_grad);
+    hipLaunchKernelGGL(ntx_softmax_kernel, dim3(1), dim3(1024), 0, st, rows, batch_len, tau, grad_scale, (const double*)S,
+                       (const double*)na2, (const double*)np2, Ga, Gp, s1, s2, out3, loss_out, want_grad);
     ZNS_LAUNCH_CHECK();
     if (want_grad) {
         hipLaunchKernelGGL(ntx_grad_kernel, dim3((unsigned)((D + 255) / 256), (unsigned)rows, 2), dim3(256), 0, st, a, p,
-                           rows, D, (const float*)na2, (const float*)np2, (const float*)Ga, (const float*)Gp,
-                           (const float*)s1, (const float*)s2, ga, gp);
+                           rows, D, (const double*)na2, (const double*)np2, (const double*)Ga, (const double*)Gp,
+                           (const double*)s1, (const double*)s2, ga, gp);
         ZNS_LAUNCH_CHECK();
     }
+    return ZNS_OK;
+}
+
+int zns_scale_f32(const float* scale, const float* x0, float* y0, size_t n0, const float* x1, float* y1, size_t n1,
+                  void* stream) {
+    ZNS_CHECK_ARG(scale != nullptr && (n0 == 0 || (x0 && y0)) && (n1 == 0 || (x1 && y1)), "scale: null pointer");
+    if (n0 + n1 == 0) return ZNS_OK;
+    const size_t want = (n0 + n1 + 255) / 256;
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)(want > 2048 ? 2048 : want)), dim3(256), 0, (hipStream_t)stream, scale,
+                       x0, y0, n0, x1, y1, n1);
+    ZNS_LAUNCH_CHECK();
     return ZNS_OK;
 }
 

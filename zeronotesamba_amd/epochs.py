@@ -33,7 +33,7 @@ class _BCEFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss):
         (dout,) = ctx.saved_tensors
-        return dout * dloss, None
+        return _ops.scale_by(dloss, dout), None
 
 
 def bce_loss(output: torch.Tensor, target: torch.Tensor) -> torch.Tensor:

@@ -16,24 +16,28 @@ from .. import _lib, _ops
 
 class _NTXentFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, anchors, poss, batch_len, temperature):
+    def forward(ctx, anchors, poss, batch_len, temperature, out3=None):
+        """out3: where the (loss, pos cos, neg cos) triple goes (a row of an epoch's statistics table), or None."""
         a = anchors.contiguous()
         p = poss.contiguous()
         rows, D = a.shape
-        out3 = torch.empty(3, dtype=torch.float32, device=a.device)
+        if out3 is None:
+            out3 = torch.empty(3, dtype=torch.float32, device=a.device)
+        loss = torch.empty((), dtype=torch.float32, device=a.device)     # written by the kernel beside out3[0]: no copy
         need = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
         ga = torch.empty_like(a) if need else None
         gp = torch.empty_like(p) if need else None
-        _ops.ntxent(a, p, rows, D, batch_len, temperature, out3, ga, gp)
+        _ops.ntxent(a, p, rows, D, batch_len, temperature, out3, ga, gp, loss_out=loss)
         if need:
             ctx.save_for_backward(ga, gp)
         ctx.mark_non_differentiable(out3)
-        return out3[0].clone(), out3
+        return loss, out3
 
     @staticmethod
     def backward(ctx, dloss, _dstats):
         ga, gp = ctx.saved_tensors
-        return ga * dloss, gp * dloss, None, None
+        da, dp = _ops.scale_by(dloss, ga, gp)      # d(loss) may be any device scalar: applied on the device, one launch
+        return da, dp, None, None, None
 
 
 class NTXent(nn.Module):

@@ -23,51 +23,58 @@ def _fresh_seed() -> int:
     return int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
 
 
-def _apply_stack(x, nbr, B, drop_p, seed, with_head, *params):
+def _apply_stack(x, x1, nbr, B, drop_p, seed, with_head, *params):
     """_StackFn.apply with the caller's grad mode passed in (autograd switches it off inside forward(), and
     ctx.needs_input_grad only reflects requires_grad): under torch.no_grad() -- val_epoch, inference -- nothing is saved
     for a backward pass."""
-    return _StackFn.apply(x, nbr, B, drop_p, seed, with_head, torch.is_grad_enabled(), *params)
+    return _StackFn.apply(x, x1, nbr, B, drop_p, seed, with_head, torch.is_grad_enabled(), *params)
 
 
 class _StackFn(torch.autograd.Function):
     """nbr DS_CNN stacks (conv stack [+ head]) as one autograd node.
 
-    forward(x [nbr*B,1,96,T], nbr, B, drop_p, seed, with_head, grad_on, *params) -> emb [nbr*B,T] (or h [nbr*B,128,T])
+    forward(x [nbr*B,1,96,T], x1, nbr, B, drop_p, seed, with_head, grad_on, *params) -> emb [nbr*B,T] (or h [nbr*B,128,T])
+    x1: None, or -- Pretext_CNN, whose caller hands two tensors (models.py:119-122) -- the positives [B,1,96,T] with x the
+        anchors: the first layer's kernels take both pointers (no torch.cat), the node then RETURNS the two embeddings as two
+        tensors (halves of one buffer) and its backward takes their two gradients as they come (no slice-backward fills, no
+        cat): the path from the caller's tensors to the parameter gradients launches no ATen kernel.
     drop_p: dropout probability of this call (the module's `dp.p` in train mode, 0 in eval mode).
     grad_on: torch.is_grad_enabled() at the call site (see _apply_stack).
     """
 
     @staticmethod
-    def forward(ctx, x, nbr, B, drop_p, seed, with_head, grad_on, *params):
+    def forward(ctx, x, x1, nbr, B, drop_p, seed, with_head, grad_on, *params):
         P = _ops.StackParams.from_flat(params, nbr)
-        pneeds = ctx.needs_input_grad[7:]
+        pneeds = ctx.needs_input_grad[8:]
         need_grad = any(pneeds) and bool(grad_on)
         drop_p = float(drop_p)
-        emb, acts, argm = _ops.stack_forward(x, P, B, drop_p, seed, save=need_grad, with_head=with_head)
+        emb, acts, argm = _ops.stack_forward(x, P, B, drop_p, seed, save=need_grad, with_head=with_head, x1=x1)
         ctx.nbr, ctx.B, ctx.with_head = nbr, B, with_head
+        ctx.pair = x1 is not None
         ctx.inv_keep = 1.0 / (1.0 - drop_p)
         ctx.conv_needs = any(n for i, n in enumerate(pneeds) if (i % 18) < 16)
         ctx.pneeds = pneeds
         if need_grad:
             ctx.n_acts = len(acts)
             ctx.argm_keys = sorted(argm.keys())
-            ctx.save_for_backward(x, emb if with_head else acts[-1], *acts, *[argm[k] for k in ctx.argm_keys],
+            ctx.save_for_backward(x, x1, emb if with_head else acts[-1], *acts, *[argm[k] for k in ctx.argm_keys],
                                   *params)
         if with_head:
+            if ctx.pair:
+                return emb[:B], emb[B:]
             return emb
         return acts[-1].reshape(acts[-1].shape[0], 128, -1)
 
     @staticmethod
-    def backward(ctx, dout):
-        if ctx.needs_input_grad[0]:
+    def backward(ctx, dout, dout1=None):
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             raise NotImplementedError("zeronotesamba_amd: gradient w.r.t. the input spectrogram is not provided "
                                       "(the reference never differentiates through the VQT)")
         saved = ctx.saved_tensors
-        x, out = saved[0], saved[1]
-        acts = list(saved[2:2 + ctx.n_acts])
-        ams = saved[2 + ctx.n_acts:2 + ctx.n_acts + len(ctx.argm_keys)]
-        params = saved[2 + ctx.n_acts + len(ctx.argm_keys):]
+        x, x1, out = saved[0], saved[1], saved[2]
+        acts = list(saved[3:3 + ctx.n_acts])
+        ams = saved[3 + ctx.n_acts:3 + ctx.n_acts + len(ctx.argm_keys)]
+        params = saved[3 + ctx.n_acts + len(ctx.argm_keys):]
         argm = dict(zip(ctx.argm_keys, ams))
         P = _ops.StackParams.from_flat(params, ctx.nbr)
         grads = [torch.empty_like(p) for p in params]
@@ -75,7 +82,8 @@ class _StackFn(torch.autograd.Function):
         dout = dout.contiguous()
         if ctx.with_head:
             _ops.stack_backward(x, P, ctx.B, acts, argm, out, dout, None, ctx.inv_keep, G,
-                                conv_grads=ctx.conv_needs)
+                                conv_grads=ctx.conv_needs, x1=x1,
+                                demb1=dout1.contiguous() if ctx.pair else None)
         else:
             # standalone _CNN: ReLU/dropout backward of cv8 on the incoming gradient (rare path, host glue)
             h = acts[7]
@@ -89,7 +97,7 @@ class _StackFn(torch.autograd.Function):
                 out_grads.append(None)
             else:
                 out_grads.append(grads[i])
-        return (None, None, None, None, None, None, None, *out_grads)
+        return (None, None, None, None, None, None, None, None, *out_grads)
 
 
 def _prep_input(x: torch.Tensor, what: str) -> torch.Tensor:
@@ -149,7 +157,7 @@ class _CNN(nn.Module):
         dummy = [params[0].new_zeros(1), params[0].new_zeros(1)]  # head slots, unused when with_head=False
         drop_p = self.drop_p()
         seed = _fresh_seed() if drop_p > 0.0 else 0
-        return _apply_stack(x, 1, x.shape[0], drop_p, seed, False, *params, *dummy)
+        return _apply_stack(x, None, 1, x.shape[0], drop_p, seed, False, *params, *dummy)
 
 
 class DS_CNN(nn.Module):
@@ -176,7 +184,7 @@ class DS_CNN(nn.Module):
         x = _prep_input(x, "DS_CNN input")
         drop_p = self.pretrained.drop_p()
         seed = _fresh_seed() if drop_p > 0.0 else 0
-        return _apply_stack(x, 1, x.shape[0], drop_p, seed, True, *self.stack_params())
+        return _apply_stack(x, None, 1, x.shape[0], drop_p, seed, True, *self.stack_params())
 
 
 class Pretext_CNN(nn.Module):
@@ -204,11 +212,9 @@ class Pretext_CNN(nn.Module):
             # the device its input and weights live on (every C-ABI call switches to its tensors' device, _ops.on_device)
             return self.anchor(anc), self.postve(pos)
         B = anc.shape[0]
-        x = torch.cat([anc, pos], dim=0)
         seed = _fresh_seed() if drop_p > 0.0 else 0
-        emb = _apply_stack(x, 2, B, drop_p, seed, True, *self.anchor.stack_params(),
-                             *self.postve.stack_params())
-        return emb[:B], emb[B:]
+        return _apply_stack(anc, pos, 2, B, drop_p, seed, True, *self.anchor.stack_params(),
+                            *self.postve.stack_params())
 
 
 class _DownFn(torch.autograd.Function):

@@ -41,16 +41,42 @@ def _branch_devices(model: torch.nn.Module, pt_task: str):
     return d, d
 
 
+class _StatsLog:
+    """The (loss, pos cos, neg cos) triples of an epoch's steps: the NT-Xent kernel writes each straight into a row of a
+    device table, and the epoch means are ONE reduction at the end -- no per-step accumulate launches, no host sync (the
+    reference adds three `.item()`s per step, pretext.py:513-515)."""
+
+    def __init__(self, device, rows: int = 1024):
+        self.device, self.rows, self.tables, self.n = device, rows, [], 0
+
+    def row(self) -> torch.Tensor:
+        i = self.n % self.rows
+        if i == 0:
+            self.tables.append(torch.empty((self.rows, 3), dtype=torch.float32, device=self.device))
+        self.n += 1
+        return self.tables[-1][i]
+
+    def means(self, empty=float("nan")) -> Tuple[float, float, float]:
+        if self.n == 0:
+            return (empty, empty, empty)
+        tot = None
+        for k, t in enumerate(self.tables):
+            used = min(self.rows, self.n - k * self.rows)
+            s = t[:used].double().sum(0)
+            tot = s if tot is None else tot + s
+        l, p, ng = (tot / self.n).tolist()
+        return l, p, ng
+
+
 def train_epoch(model: torch.nn.Module, train_loader: Iterable, criterion: NTXent,
                 optimizer: torch.optim.Optimizer, pt_task: str = "zerons") -> Tuple[torch.nn.Module, float, float, float]:
     """pretext.py:453-524."""
     if pt_task not in ("zerons", "clmr"):
         raise ValueError("Which pretext task are we running?")
     device0, device1 = _branch_devices(model, pt_task)
-    acc = torch.zeros(3, dtype=torch.float64, device=device1)
+    log = _StatsLog(device1)
     model.train()
-    batch_idx = -1
-    for batch_idx, [batch] in enumerate(train_loader):
+    for [batch] in train_loader:
         anchors, postves = split_batch(batch, device0, device1)
         optimizer.zero_grad()
         if pt_task == "zerons":
@@ -59,12 +85,10 @@ def train_epoch(model: torch.nn.Module, train_loader: Iterable, criterion: NTXen
         else:  # clmr: one shared DS_CNN on both views (pretext.py:494-511)
             anc_emb = model(anchors)
             pos_emb = model(postves)
-        loss, stats = _loss_and_stats(criterion, anc_emb, pos_emb)
+        loss, _ = _loss_and_stats(criterion, anc_emb, pos_emb, log.row())
         loss.backward()
         optimizer.step()
-        acc += stats.double()
-    n = batch_idx + 1
-    l, p, ng = (acc / n).tolist()
+    l, p, ng = log.means()
     print("*** Mean training batch loss is {:.3f}.".format(l))
     print("*** Mean training anchor / positive similiarity is {:.3f}.".format(p))
     print("*** Mean training anchor / negative similiarity is {:.3f}.".format(ng))
@@ -77,12 +101,11 @@ def val_epoch(model: torch.nn.Module, val_loader: Iterable, criterion: NTXent,
     if pt_task not in ("zerons", "clmr"):
         raise ValueError("Which pretext task are we running?")
     device0, device1 = _branch_devices(model, pt_task)
-    acc = torch.zeros(3, dtype=torch.float64, device=device1)
+    log = _StatsLog(device1)
     model.eval()
-    batch_idx = -1
     # nothing writes the weights inside this loop: the packed weight operands are built once for the whole epoch
     with torch.no_grad(), _ops.frozen_weights():
-        for batch_idx, [batch] in enumerate(val_loader):
+        for [batch] in val_loader:
             anchors, postves = split_batch(batch, device0, device1)
             if optimizer is not None:
                 optimizer.zero_grad()        # pretext.py:552,572 clear the gradients here too
@@ -92,19 +115,16 @@ def val_epoch(model: torch.nn.Module, val_loader: Iterable, criterion: NTXent,
             else:
                 anc_emb = model(anchors)
                 pos_emb = model(postves)
-            _, stats = _loss_and_stats(criterion, anc_emb, pos_emb)
-            acc += stats.double()
-    n = batch_idx + 1
-    l, p, ng = (acc / n).tolist()
-    return l, p, ng
+            _loss_and_stats(criterion, anc_emb, pos_emb, log.row())
+    return log.means()
 
 
-def _loss_and_stats(criterion: NTXent, a: torch.Tensor, p: torch.Tensor):
-    """criterion(a, p) without the device->host copy of the two cosine means."""
+def _loss_and_stats(criterion: NTXent, a: torch.Tensor, p: torch.Tensor, out3: Optional[torch.Tensor] = None):
+    """criterion(a, p) without the device->host copy of the two cosine means; the triple goes to `out3` when given."""
     from .models.loss_functions import _NTXentFn
     if a.shape[0] > criterion.batch_len:
         raise IndexError(f"NTXent: {a.shape[0]} rows > batch_len={criterion.batch_len}")
-    loss, stats = _NTXentFn.apply(a, p, criterion.batch_len, criterion.temperature)
+    loss, stats = _NTXentFn.apply(a, p, criterion.batch_len, criterion.temperature, out3)
     return loss, stats
 
 
@@ -340,8 +360,10 @@ class PretextTrainer:
         b = batch.to(dev, non_blocking=True)
         return b.transpose(0, 1).reshape(2 * b.shape[0], 1, b.shape[2], b.shape[3]).contiguous()
 
-    def step(self, x: torch.Tensor, update: bool = True, accumulate: bool = False) -> torch.Tensor:
-        """x: [2B,1,96,T] branch-major.  Returns a device tensor (loss, mean pos cos, mean neg cos); no host sync.
+    def step(self, x: torch.Tensor, update: bool = True, accumulate: bool = False,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x: [2B,1,96,T] branch-major.  Returns a device tensor (loss, mean pos cos, mean neg cos) -- `out` when given (three
+        contiguous float32: a row of an epoch's statistics table) -- ; no host sync.
         update=False leaves the gradient of this batch in `flat_g` and the parameters alone; accumulate=True ADDS this
         batch's gradient to what `flat_g` holds (the backward-weights kernels accumulate in place) -- gradient
         accumulation over k batches is `step(x1, update=False)`, `step(x2, update=False, accumulate=True)`, ...,
@@ -356,15 +378,16 @@ class PretextTrainer:
             raise IndexError(f"PretextTrainer: {B} rows > batch_len={self.batch_len}")
         _ops.same_device(self.flat_p, (x,), "PretextTrainer.step")
         with _ops.on_device(x):
-            return self._step(x, B, T, update, accumulate)
+            return self._step(x, B, T, update, accumulate, out)
 
-    def _step(self, x: torch.Tensor, B: int, T: int, update: bool, accumulate: bool = False) -> torch.Tensor:
+    def _step(self, x: torch.Tensor, B: int, T: int, update: bool, accumulate: bool = False,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
         drop_p = self._drop_p()
         inv_keep = 1.0 / (1.0 - drop_p)
         seed = self._next_seed()
         Bs = 2 * B // self.nbr     # rows per stack: B for the twin launch, 2B for the shared (clmr) network
         emb, acts, argm = _ops.stack_forward(x, self.P, Bs, drop_p, seed, save=True)
-        out3 = torch.empty(3, dtype=torch.float32, device=x.device)
+        out3 = out if out is not None else torch.empty(3, dtype=torch.float32, device=x.device)
         demb = torch.empty_like(emb)
         _ops.ntxent(emb[:B], emb[B:], B, T, self.batch_len, self.temperature, out3, demb[:B], demb[B:])
         hook = self.reducer.layer_done if self.reducer is not None else None
@@ -392,41 +415,35 @@ class PretextTrainer:
         self._params_written()
 
     @torch.no_grad()
-    def evaluate(self, x: torch.Tensor) -> torch.Tensor:
+    def evaluate(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """(loss, mean pos cos, mean neg cos) of one branch-major batch without dropout and without a backward pass.
         Inside a `_ops.frozen_weights()` block (evaluate_epoch holds one) the packed weight operands are reused."""
         B = x.shape[0] // 2
         T = x.shape[-1]
         _ops.same_device(self.flat_p, (x,), "PretextTrainer.evaluate")
         emb, _, _ = _ops.stack_forward(x, self.P, 2 * B // self.nbr, 0.0, 0, save=False)
-        out3 = torch.empty(3, dtype=torch.float32, device=x.device)
+        out3 = out if out is not None else torch.empty(3, dtype=torch.float32, device=x.device)
         _ops.ntxent(emb[:B], emb[B:], B, T, self.batch_len, self.temperature, out3, None, None)
         return out3
 
     def evaluate_epoch(self, loader: Iterable) -> Tuple[float, float, float]:
         """Fused equivalent of pretext.val_epoch (pretext.py:527-592): mean (loss, pos cos, neg cos) over the loader."""
-        acc = torch.zeros(3, dtype=torch.float64, device=self.flat_p.device)
-        n = 0
+        log = _StatsLog(self.flat_p.device)
         with _ops.frozen_weights():
             for item in loader:
                 x = item if torch.is_tensor(item) else self.stack_inputs(item[0])
-                acc += self.evaluate(x).double()
-                n += 1
-        l, p, ng = (acc / max(n, 1)).tolist()
-        return l, p, ng
+                self.evaluate(x, out=log.row())
+        return log.means(empty=0.0)
 
     def train_epoch(self, loader: Iterable) -> Tuple[float, float, float]:
         """Fused equivalent of pretext.train_epoch: returns (mean loss, mean pos cos, mean neg cos).
         `loader` yields either the reference's `[batch]` with batch [B,2,96,T] (DataLoader over a TensorDataset) or
         branch-major device tensors [2B,1,96,T] (ShiftBank.batches)."""
-        acc = torch.zeros(3, dtype=torch.float64, device=self.flat_p.device)
-        n = 0
+        log = _StatsLog(self.flat_p.device)
         for item in loader:
             x = item if torch.is_tensor(item) else self.stack_inputs(item[0])
-            acc += self.step(x).double()
-            n += 1
-        l, p, ng = (acc / max(n, 1)).tolist()
-        return l, p, ng
+            self.step(x, out=log.row())
+        return log.means(empty=0.0)
 
 
 # ---------------------------------------------------------------------------------------------------------------
