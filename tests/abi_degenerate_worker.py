@@ -162,19 +162,25 @@ def small():
 
     def ntx(ov):
         a = {"rows": rows, "D": D, "batch_len": 16, **ov}
-        return L.zns_ntxent_f32(dp(ea), dp(ep), a["rows"], a["D"], a["batch_len"], C.c_float(0.1), dp(out3), dp(ga), dp(gp),
+        return L.zns_ntxent_f32(dp(ea), dp(ep), a["rows"], a["D"], a["batch_len"], C.c_float(0.1), dp(out3), None, dp(ga), dp(gp),
                                 C.c_float(1.0), dp(nws), nws.numel(), None)
 
     sweep("ntxent", ntx, ["rows", "D", "batch_len"], {})
-    assert L.zns_ntxent_f32(dp(ea), dp(ep), rows, D, 16, C.c_float(0.1), dp(out3), dp(ga), dp(gp), C.c_float(1.0), dp(nws), 64,
+    assert L.zns_ntxent_f32(dp(ea), dp(ep), rows, D, 16, C.c_float(0.1), dp(out3), None, dp(ga), dp(gp), C.c_float(1.0), dp(nws), 64,
                             None) != 0
-    assert L.zns_ntxent_f32(dp(ea), dp(ep), 2049, D, 4096, C.c_float(0.1), dp(out3), None, None, C.c_float(1.0), dp(nws),
+    assert L.zns_ntxent_f32(dp(ea), dp(ep), 2049, D, 4096, C.c_float(0.1), dp(out3), None, None, None, C.c_float(1.0), dp(nws),
                             nws.numel(), None) != 0
 
     o, t = torch.rand(1, 77, device=DEV), (torch.rand(1, 77, device=DEV) > 0.5).float()
     loss, dout = torch.empty(1, device=DEV), torch.empty_like(o)
     assert L.zns_bce_f32(dp(o), dp(t), 77, dp(loss), dp(dout), C.c_float(1.0), None) == 0
     assert L.zns_bce_f32(dp(o), dp(t), 0, dp(loss), dp(dout), C.c_float(1.0), None) != 0
+    # zns_scale_f32: null pointers with a non-zero count are refused, empty arrays are a no-op
+    assert L.zns_scale_f32(dp(loss), dp(o), dp(dout), 77, None, None, 0, None) == 0
+    assert L.zns_scale_f32(dp(loss), dp(o), dp(dout), 0, None, None, 0, None) == 0
+    assert L.zns_scale_f32(None, dp(o), dp(dout), 77, None, None, 0, None) != 0
+    assert L.zns_scale_f32(dp(loss), None, dp(dout), 77, None, None, 0, None) != 0
+    assert L.zns_scale_f32(dp(loss), dp(o), dp(dout), 77, None, None, 5, None) != 0
 
     p, gr, m, v = f32(1001), f32(1001), torch.zeros(1001, device=DEV), torch.zeros(1001, device=DEV)
 

@@ -114,7 +114,7 @@ def test_bench_eight_ranks_dry_run_on_one_gpu():
     r = json.loads(lines[0])
     c = r["config"]
     assert r["n_gpus"] == 8 and c["global_batch"] == 128 and c["parallelism"] == "dp8" and r["scaling"] == "weak"
-    assert c["allreduce_buckets"] == 6 and c["allreduce_bytes"] == 26819202 * 4
+    assert c["allreduce_buckets"] == 6 and 26819202 * 4 <= c["allreduce_bytes"] <= 26819202 * 4 + 256
     assert "comm_exposed_ms" in c and c["ms_per_step_without_allreduce"] > 0
     assert c["replicas_identical_after_timed_region"] is True
     assert abs(r["value"] - 8 * 1000.0 / r["ms_per_step"]) < 1e-6 * r["value"]

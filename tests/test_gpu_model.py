@@ -493,7 +493,8 @@ def _kernel_names(fn, warm=2):
     with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
         fn()
         torch.cuda.synchronize()
-    names = [e.name for e in prof.events() if str(getattr(e, "device_type", "")).endswith("CUDA")]
+    names = [e.name for e in prof.events() if str(getattr(e, "device_type", "")).endswith("CUDA")
+             and not getattr(e, "is_user_annotation", False) and "#" not in e.name]      # kernels, not annotation ranges
     if not names:
         pytest.skip("torch.profiler records no device kernels on this box")
     return names

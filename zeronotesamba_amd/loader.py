@@ -1,12 +1,12 @@
-"""Drop-in for /root/reference/zeroNoteSamba/loader.py::load_models on MI355X.
+"""`load_models(_status, _pre, _lr)` for the MI355X kernels: the downstream model, its loss and its optimizer.
 
-Same arguments and return triple `(criterion, optimizer, model)`, same checkpoint names, freezing rule
-(loader.py:29-34: `requires_grad = False` on `*.pretrained`) and learning-rate rules (loader.py:36-43, 55-62, 66):
-frozen -> lr, fine-tune of the pretext weights -> 0.5*lr*10e-2, CLMR fine-tune -> 0.5*lr, vanilla -> lr.
-The model is the HIP-backed Down_CNN / DS_CNN, the criterion the fused BCE kernel, the optimizer the fused Adam.
-`state_dict` lets a caller pass already-loaded weights (the .pth files are not shipped with this repository).
+Mirrors what /root/reference/zeroNoteSamba/loader.py:8-69 decides -- which network, which checkpoint, which sub-modules
+are frozen, which learning rate -- as a table (`RULES`) instead of a chain of branches; the objects it returns are this
+package's own: the HIP-backed `Down_CNN` / `DS_CNN`, the fused BCE kernel (`epochs.BCELoss`) and the fused multi-tensor
+`optim.Adam`.  The reference loads the checkpoints from fixed paths relative to the working directory; the .pth files do not
+ship with either repository, so a caller may hand the weights in (`state_dict=`).
 """
-from typing import Dict, Optional, Tuple
+from typing import Callable, Dict, NamedTuple, Optional, Sequence, Tuple
 
 import torch
 
@@ -16,51 +16,47 @@ from .optim import Adam
 
 SHIFT_CKPT = "models/saved/shift_pret_cnn_16.pth"   # loader.py:25
 CLMR_CKPT = "models/saved/clmr_pret_cnn_16.pth"     # loader.py:48
+BETAS = (0.9, 0.999)                                # loader.py:39,43,58,62,66
+
+
+class _Rule(NamedTuple):
+    build: Callable[[], torch.nn.Module]            # the network
+    checkpoint: Optional[str]                       # file the reference reads its weights from (None: random init)
+    load_into: Callable[[torch.nn.Module], torch.nn.Module]     # the sub-module that takes the checkpoint
+    backbones: Callable[[torch.nn.Module], Sequence[torch.nn.Module]]   # what `_pre == "frozen"` freezes
+    finetune_lr: Callable[[float], float]           # learning rate when the backbone trains too
+
+
+# _status -> rule.  Anything that is neither "pretrained" nor "clmr" ("vanilla", "samplecnn", ...) is a randomly
+# initialised DS_CNN trained at `_lr` (loader.py:64-66).
+RULES: Dict[str, _Rule] = {
+    # zeroNoteSamba's own pretext weights under Down_CNN (loader.py:22-43): both branches' conv stacks freeze; fine-tuning
+    # runs at 0.5 * lr * 10e-2 (the literal of loader.py:43: a twentieth of lr)
+    "pretrained": _Rule(Down_CNN, SHIFT_CKPT, lambda m: m.pretext,
+                        lambda m: (m.pretext.anchor.pretrained, m.pretext.postve.pretrained), lambda lr: 0.5 * lr * 10e-2),
+    # the CLMR baseline: one DS_CNN (loader.py:45-62); fine-tuning at half of lr
+    "clmr": _Rule(DS_CNN, CLMR_CKPT, lambda m: m, lambda m: (m.pretrained,), lambda lr: 0.5 * lr),
+}
+_FROM_SCRATCH = _Rule(DS_CNN, None, lambda m: m, lambda m: (), lambda lr: lr)
 
 
 def load_models(_status: str, _pre: str, _lr: float, state_dict: Optional[Dict[str, torch.Tensor]] = None,
                 device: str = "cuda") -> Tuple[BCELoss, torch.optim.Optimizer, torch.nn.Module]:
-    """
-    Function for loading loss, optimizer, and model.
-    -- _status: pretrained, vanilla, clmr, or samplecnn?
-    -- _pre: frozen weights
-    -- _lr: learning rate
-    """
-    criterion = BCELoss()
-    model: torch.nn.Module
-
-    print("\n{} learning mode...".format(_status))
-
-    if _status == "pretrained":
-        model = Down_CNN().to(device)
-        if state_dict is None:
-            state_dict = torch.load(SHIFT_CKPT, map_location=torch.device(device))
-        model.pretext.load_state_dict(state_dict)
-
-        if _pre == "frozen":
-            for param in model.pretext.anchor.pretrained.parameters():
-                param.requires_grad = False
-            for param in model.pretext.postve.pretrained.parameters():
-                param.requires_grad = False
-            optimizer = Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=_lr, betas=(0.9, 0.999))
-        else:
-            optimizer = Adam(model.parameters(), lr=0.5 * _lr * 10e-2, betas=(0.9, 0.999))
-
-    elif _status == "clmr":
-        model = DS_CNN().to(device)
-        if state_dict is None:
-            state_dict = torch.load(CLMR_CKPT, map_location=torch.device(device))
-        model.load_state_dict(state_dict)
-
-        if _pre == "frozen":
-            for param in model.pretrained.parameters():
-                param.requires_grad = False
-            optimizer = Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=_lr, betas=(0.9, 0.999))
-        else:
-            optimizer = Adam(model.parameters(), lr=0.5 * _lr, betas=(0.9, 0.999))
-
+    """Returns `(criterion, optimizer, model)` like the reference.
+    _status: "pretrained" | "clmr" | anything else (a DS_CNN from scratch);  _pre: "frozen" freezes the rule's backbones and
+    trains the rest at `_lr`, any other value fine-tunes everything at the rule's reduced rate;  _lr: base learning rate.
+    state_dict: weights to use instead of reading the rule's checkpoint file;  device: where the model lives."""
+    rule = RULES.get(_status, _FROM_SCRATCH)
+    print("\n{} learning mode...".format(_status))          # the reference announces the mode (loader.py:19)
+    model = rule.build().to(device)
+    if rule.checkpoint is not None:
+        weights = state_dict if state_dict is not None else torch.load(rule.checkpoint, map_location=torch.device(device))
+        rule.load_into(model).load_state_dict(weights)
+    if rule.checkpoint is not None and _pre == "frozen":
+        for backbone in rule.backbones(model):
+            backbone.requires_grad_(False)
+        trainable = [p for p in model.parameters() if p.requires_grad]
+        optimizer = Adam(trainable, lr=_lr, betas=BETAS)
     else:
-        model = DS_CNN().to(device)
-        optimizer = Adam(model.parameters(), lr=_lr, betas=(0.9, 0.999))
-
-    return criterion, optimizer, model
+        optimizer = Adam(model.parameters(), lr=rule.finetune_lr(_lr), betas=BETAS)
+    return BCELoss(), optimizer, model

@@ -31,10 +31,13 @@ class _NTXentFn(torch.autograd.Function):
         if need:
             ctx.save_for_backward(ga, gp)
         ctx.mark_non_differentiable(out3)
+        ctx.set_materialize_grads(False)      # no zero-filled "gradient" of the statistics triple handed to backward
         return loss, out3
 
     @staticmethod
     def backward(ctx, dloss, _dstats):
+        if dloss is None:
+            return None, None, None, None, None
         ga, gp = ctx.saved_tensors
         da, dp = _ops.scale_by(dloss, ga, gp)      # d(loss) may be any device scalar: applied on the device, one launch
         return da, dp, None, None, None
