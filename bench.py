@@ -348,14 +348,19 @@ def measure_finetune(dev, cpu: bool, iters: int = 10) -> dict:
 
 def cu_masked_stream(dev, reserve_per_xcd: int = 1):
     """A HIP stream whose kernels may not use `reserve_per_xcd` CUs of every XCD (hipExtStreamCreateWithCUMask: one bit per
-    CU, 32-bit words; on MI355X bits [32 i, 32 i + 32) are XCD i's CUs, tools/exp_cu_mask.py), wrapped so that torch -- and
-    with it every launch of the trainer, which enqueues on torch's current stream -- can use it."""
+    CU, 32-bit words), wrapped so that torch -- and with it every launch of the trainer, which enqueues on torch's current
+    stream -- can use it.  Mask bit n is a CU of XCD n % 8 (the driver deals the bits round-robin over the XCDs), MEASURED on
+    the box with tools/ubench_cu_mask.hip (profiles/r05_ubench_cu_mask.txt): clearing bits 0..7 leaves 31 CUs in every XCD;
+    clearing bits 31, 63, .. 255 -- what round 4 did, believing bits [32 i, 32 i + 32) to be XCD i -- takes eight CUs from
+    XCD 7 alone."""
     import ctypes
     ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    n_xcd = 8
     words = [0xFFFFFFFF] * ((ncu + 31) // 32)
-    for i in range(len(words)):
-        for k in range(reserve_per_xcd):
-            words[i] &= ~(1 << (31 - k))
+    for k in range(reserve_per_xcd):
+        for xcd in range(n_xcd):
+            bit = k * n_xcd + xcd                    # the k-th CU of this XCD
+            words[bit // 32] &= ~(1 << (bit % 32))
     if ncu % 32:
         words[-1] &= (1 << (ncu % 32)) - 1
     hip = ctypes.CDLL("libamdhip64.so")

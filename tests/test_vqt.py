@@ -251,6 +251,37 @@ def test_default_pyramid_arithmetic_stays_within_1e_5_of_the_exact_one(mode, n):
         assert lin_err(d[i], e[i]) < 1e-5
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["vqt", "cqt"])
+def test_default_arithmetic_log_deviation_by_bin_level(mode):
+    """The default pyramid's distance from the restated reference in the LOG domain (what the network consumes), by how loud
+    a bin is relative to the loudest of its spectrogram -- the explicit form of `within_contract`'s `1e-4 |V| + 1e-6 max|V|`:
+        bins within 1e-2 of the loudest   |log V - log V_ref| <= 1e-4 + 1e-6 / 1e-2 = 2e-4
+        within 1e-3                        <= 1.1e-3
+        within 1e-4                        <= 1.01e-2
+        anything louder than the 1e-9 floor: bounded by the linear contract only
+    and what the 10 s / 5 s test signals actually show (printed; the exact pyramid, `exact=True`, keeps 1e-4 everywhere)."""
+    from zeronotesamba_amd.processing.input_rep import generate_XQT
+    worst = {1e-2: 0.0, 1e-3: 0.0, 1e-4: 0.0, 0.0: 0.0}
+    worst_exact = 0.0
+    for n in (160000, 80000):
+        y = noise(10 + n % 7, n)
+        ref = vqt_ref.generate_XQT(y, 16000, mode).astype(np.float64)
+        got = generate_XQT(y, 16000, mode).astype(np.float64)
+        ex = generate_XQT(y, 16000, mode, exact=True).astype(np.float64)
+        assert within_contract(got, ref)
+        worst_exact = max(worst_exact, float(np.abs(ex - ref).max()))
+        level = np.exp(ref) / np.exp(ref).max()
+        dev = np.abs(got - ref)
+        for lv in worst:
+            sel = level >= lv
+            worst[lv] = max(worst[lv], float(dev[sel].max()))
+    print(f"{mode}: default pyramid, worst |log deviation| for bins within 1e-2 / 1e-3 / 1e-4 of the loudest / all bins: "
+          f"{worst[1e-2]:.2e} / {worst[1e-3]:.2e} / {worst[1e-4]:.2e} / {worst[0.0]:.2e}; exact pyramid, all bins: {worst_exact:.2e}")
+    assert worst[1e-2] <= 2e-4 and worst[1e-3] <= 1.1e-3 and worst[1e-4] <= 1.01e-2
+    assert worst_exact < 1e-4
+
+
 def _pyramid_rows(ws, n_clips, n):
     """Levels 1..7 of the workspace zns_xqt_stages_f32(stages=1) fills: [level][clip] -> float32 numpy row."""
     lens, offs, o = [n], [0], 0

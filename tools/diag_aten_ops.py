@@ -11,6 +11,8 @@ from zeronotesamba_amd.optim import Adam
 DEV = "cuda:0"
 ft = len(sys.argv) > 1 and sys.argv[1] == "finetune"
 B, T = (1, 96) if ft else (4, 64)
+if len(sys.argv) > 2:
+    T = int(sys.argv[2])
 g = torch.Generator().manual_seed(3)
 both = (torch.randn((2, B, 1, 96, T), generator=g) * 3 - 6).clamp_(-20.72, 3.0).to(DEV)
 m = (Down_CNN() if ft else Pretext_CNN()).to(DEV)
@@ -32,5 +34,5 @@ with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU], with_stac
     step(); torch.cuda.synchronize()
 for e in prof.events():
     if e.name.startswith("aten::") and any(k in e.name for k in ("fill", "zero", "ones", "copy", "mul", "add", "cat", "clone", "contiguous", "to")):
-        st = [s for s in (e.stack or []) if "zeronotesamba" in s or "diag_aten" in s][:2]
+        st = [s for s in (e.stack or []) if "zeronotesamba" in s or "diag_aten" in s or "torch/" in s][:4]
         print(e.name, "|", getattr(e, "device_time_total", getattr(e, "cuda_time_total", 0)), "|", st)

@@ -506,11 +506,19 @@ def _yml(ymldict) -> Tuple[int, str, float, float]:
             float(ymldict.get("lower_p", -1.0)), float(ymldict.get("upper_p", -1.0)))
 
 
-def drum_anchor_positive(stems: Dict[str, Any], ymldict, rng=None):
+def _yml_exact(ymldict) -> bool:
+    try:
+        return bool(ymldict.get("xqt_exact", False))
+    except AttributeError:
+        return False
+
+
+def drum_anchor_positive(stems: Dict[str, Any], ymldict, rng=None, exact: bool = False):
     """
     Function for generating anchor and positive samples.
     -- stems: dictionary of stem names and signals
-    -- ymldict: YAML dictionary
+    -- ymldict: YAML dictionary (`xqt_exact: true` there selects the same as exact=True)
+    -- exact: the XQT pyramid that rounds like resampy tap by tap (processing/input_rep.py::generate_XQT_batch)
     Same 4-tuple as pretext.py:30-86 (numpy arrays): full-length anchor mix, drums, and the two XQTs of the crop.
     """
     from .processing.input_rep import generate_XQT_batch
@@ -519,7 +527,7 @@ def drum_anchor_positive(stems: Dict[str, Any], ymldict, rng=None):
     start = select_clip(anchor, pos, length, lower_p, upper_p, rng)
     n = length * 16000
     crops = torch.stack([anchor[start:start + n], pos[start:start + n]])
-    xqt = generate_XQT_batch(crops, 16000, mode)
+    xqt = generate_XQT_batch(crops, 16000, mode, exact=exact or _yml_exact(ymldict))
     return anchor.cpu().numpy(), pos.cpu().numpy(), xqt[0].cpu().numpy(), xqt[1].cpu().numpy()
 
 
@@ -528,10 +536,12 @@ def _first_pass(count: int, n_frames: int, lower_p: float, upper_p: float) -> bo
 
 
 def fill_memory_bank(all_stems: Dict[str, Dict[str, Any]], fps: Sequence[str], ymldict, rng=None,
-                     chunk: int = 256, files_per_sync: int = 32) -> torch.Tensor:
+                     chunk: int = 256, files_per_sync: int = 32, exact: bool = False) -> torch.Tensor:
     """The bank-filling loop of create_memory_bank (pretext.py:143-170) for stems that are already loaded:
     one (anchor, positive) XQT pair per file path, in `fps` order, written straight into a device-resident
     `(len(fps), 2, 96, T)` bank (feed it to ShiftBank).  Audio decoding and the pickle dump are out of scope.
+    exact (or `xqt_exact: true` in the YAML dictionary): the bank is computed ONCE and trained on for every epoch -- the XQT
+    pyramid that rounds like resampy tap by tap costs about twice the default's time here and nothing afterwards.
 
     The reference consumes ONE random stream across files (each file draws `randint(0, stop)` until its crop passes the
     RMS gate), so file i+1's draws depend on how many file i needed.  To keep that stream exact without a host round
@@ -651,5 +661,6 @@ def fill_memory_bank(all_stems: Dict[str, Dict[str, Any]], fps: Sequence[str], y
             del resident[i]
         if pos - base == chunk or pos == len(fps):                         # the chunk's rows are final: transform them
             k = pos - base
-            generate_XQT_batch(staged[:k].reshape(2 * k, n), 16000, mode, out=bank[base:pos].view(2 * k, 96, T))
+            generate_XQT_batch(staged[:k].reshape(2 * k, n), 16000, mode, out=bank[base:pos].view(2 * k, 96, T),
+                               exact=exact or _yml_exact(ymldict))
     return bank

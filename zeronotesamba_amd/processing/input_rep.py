@@ -20,12 +20,18 @@ _MODES = {"vqt": _lib.ZNS_MODE_VQT, "cqt": _lib.ZNS_MODE_CQT}
 
 
 def generate_XQT_batch(signals: torch.Tensor, sample_rate: int, mode: str, out: torch.Tensor = None,
-                       stages: int = 3, ws: torch.Tensor = None) -> torch.Tensor:
+                       stages: int = 3, ws: torch.Tensor = None, exact: bool = False) -> torch.Tensor:
     """signals: float32 [n_clips, n_samples] on a ROCm device -> float32 [n_clips, 96, 1 + n_samples//256].
     out: optional preallocated result (steady-state pipelines reuse it).  stages: 3 = the whole transform (vqt: ONE fused
     launch, the pyramid never leaves LDS; cqt: per-stage launches); 1 / 2 run the decimation pyramid / the filter bank alone on
     the shared workspace (bench.py times them separately); 3 | _lib.ZNS_XQT_SEPARATE forces the per-stage launches (same bits);
     | _lib.ZNS_XQT_EXACT selects the validation pyramid that emulates resampy's per-tap rounding bit for bit (slower).
+    exact=True is the same switch for callers that never see the flag constants: the default pyramid runs resampy's taps in
+    resampy's order with one float32 fused multiply-add per tap (bit for bit its numpy model; 1e-5 of the loudest bin and
+    `1e-4 |V| + 1e-6 max|V|` per bin from the restated reference, i.e. up to a few 1e-4 in log() in bins a thousand times
+    below the loudest -- tests/test_vqt.py::test_default_arithmetic_log_deviation_by_bin_level records the figures); the exact
+    pyramid rounds like resampy after every tap and keeps 1e-4 in log() in EVERY bin, at about twice the time.  A
+    one-time dataset or memory-bank pass that wants the reference's weak bins to the last digit asks for it.
     ws: optional caller-owned uint8 workspace of zns_xqt_workspace_bytes (a pipeline that overlaps two batches on two
     streams gives each its own; the default is one grow-only buffer per device)."""
     if mode not in _MODES:
@@ -41,6 +47,8 @@ def generate_XQT_batch(signals: torch.Tensor, sample_rate: int, mode: str, out: 
         out = torch.empty((n_clips, 96, T), dtype=torch.float32, device=x.device)
     elif tuple(out.shape) != (n_clips, 96, T) or out.dtype != torch.float32 or out.device != x.device or not out.is_contiguous():
         raise ValueError(f"generate_XQT_batch: out must be a contiguous float32 [{n_clips}, 96, {T}] tensor on {x.device}")
+    if exact:
+        stages = int(stages) | _lib.ZNS_XQT_EXACT
     if ws is None:
         ws = _ops.workspace(L.zns_xqt_workspace_bytes(n_clips, n, _MODES[mode]), x.device, slot=1)
     with _ops.on_device(x):       # the FIR bank is cached per device
@@ -53,12 +61,13 @@ def generate_XQT_batch(signals: torch.Tensor, sample_rate: int, mode: str, out: 
 
 
 def generate_XQT(signal: Union[npt.NDArray[np.float32], torch.Tensor], sample_rate: int,
-                 mode: str) -> npt.NDArray[np.float32]:
+                 mode: str, exact: bool = False) -> npt.NDArray[np.float32]:
     """
     Generates a high-resolution XQT spectrogram.
     -- signal: signal to compute XQT on (1-D float32 waveform)
     -- sample_rate: self-explanatory (16000, the reference's working rate)
     -- mode: can be either vqt or cqt
+    -- exact (not in the reference's signature): the pyramid that rounds like resampy tap by tap, see generate_XQT_batch
     """
     if mode not in _MODES:
         raise Exception("Mode can only be vqt or cqt!")
@@ -68,5 +77,5 @@ def generate_XQT(signal: Union[npt.NDArray[np.float32], torch.Tensor], sample_ra
     if sig.dim() != 1:
         raise ValueError(f"generate_XQT expects a 1-D waveform, got shape {tuple(sig.shape)}")
     dev = sig.device if sig.is_cuda else torch.device("cuda", torch.cuda.current_device())
-    out = generate_XQT_batch(sig.to(dev, dtype=torch.float32).reshape(1, -1), sample_rate, mode)
+    out = generate_XQT_batch(sig.to(dev, dtype=torch.float32).reshape(1, -1), sample_rate, mode, exact=exact)
     return out[0].cpu().numpy()
