@@ -17,6 +17,7 @@ gradients are summed over ranks and scaled by 1/world_size inside the Adam kerne
 """
 from typing import Any, Dict, Iterable, List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 
 from . import _lib, _ops
@@ -569,98 +570,122 @@ def fill_memory_bank(all_stems: Dict[str, Dict[str, Any]], fps: Sequence[str], y
     row_len = 3 + MAX_OTHER
     chunk = max(1, min(chunk, len(fps)))
 
-    resident = {}                 # file index -> (others, drums) on the device: a file speculated behind a miss is not uploaded twice
+    N = len(fps)
+    # ---- every file is walked ONCE: its stems validated, their device pointers recorded in a numpy table, so that a group's
+    # crop table is three array assignments; the walk over the NEXT group's files runs while the GPU works on the current one
+    ptrs = np.zeros((chunk, 1 + MAX_OTHER), dtype=np.int64)       # [drums, other stems in dict order ...]
+    n_oth = np.zeros(chunk, dtype=np.int64)
+    lens = [0] * chunk
+    alive: list = [None] * chunk                                   # (others, drums) of the chunk's files: keeps uploads alive
     dev = None
 
-    def signals(i):
-        """(other stems in dict order, drums) of file i as device float32 vectors (no copy when they already are)."""
-        if i in resident:
-            return resident[i]
-        stems = all_stems[fps[i].strip()]
-        others, drums = [], None
-        for name, sig in stems.items():
-            t = sig if (torch.is_tensor(sig) and sig.is_cuda and sig.dtype == torch.float32 and sig.dim() == 1
-                        and sig.is_contiguous()) else to_device_signal(sig, f"stem {name!r}")
-            if name == "drums":
-                drums = t
-            else:
-                others.append(t)
-        if not others:
-            raise Exception("Anchor is still None.")
-        if drums is None:
-            raise KeyError("stems has no 'drums' entry")
-        if len(others) > MAX_OTHER:
-            raise ValueError(f"more than {MAX_OTHER} non-drum stems")
-        m = drums.numel()
-        if any(o.numel() != m for o in others):
-            raise ValueError("all stems must have the same length")
-        if m - n - 1 < 0:
-            raise ValueError(f"signal of {m} samples is shorter than a {length} s clip")
-        # the crop table hands raw pointers to zns_stage_crops_f32, which cannot tell whose memory they are
-        _ops.same_device(drums if dev is None else staged, others + [drums], f"stems of {fps[i].strip()!r}")
-        resident[i] = (others, drums)
-        return others, drums
+    loaded = 0                                                     # rows [0, loaded) of the current chunk are in the tables
 
-    dev = signals(0)[1].device
-    bank = torch.empty((len(fps), 2, 96, T), dtype=torch.float32, device=dev)
+    def load_rows(base: int, upto: int) -> None:
+        nonlocal dev, loaded
+        for k in range(loaded, min(upto, chunk, N - base)):
+            ptrs[k] = 0
+            name_ = fps[base + k].strip()
+            others, drums = [], None
+            for name, sig in all_stems[name_].items():
+                t = sig if (type(sig) is torch.Tensor and sig.is_cuda and sig.dtype == torch.float32 and sig.dim() == 1
+                            and sig.is_contiguous()) else to_device_signal(sig, f"stem {name!r}")
+                if name == "drums":
+                    drums = t
+                else:
+                    others.append(t)
+            if not others:
+                raise Exception("Anchor is still None.")
+            if drums is None:
+                raise KeyError("stems has no 'drums' entry")
+            if len(others) > MAX_OTHER:
+                raise ValueError(f"more than {MAX_OTHER} non-drum stems")
+            m = drums.numel()
+            if dev is None:
+                dev = drums.device
+            for q, o in enumerate(others):
+                if o.numel() != m:
+                    raise ValueError("all stems must have the same length")
+                if o.device != dev:       # the crop table hands raw pointers to zns_stage_crops_f32, which cannot tell whose memory they are
+                    _ops.same_device(drums, [o], f"stems of {name_!r}")
+                ptrs[k, 1 + q] = o.data_ptr()
+            if drums.device != dev:
+                raise RuntimeError(f"zeronotesamba_amd: stems of {name_!r}: tensors on different devices ({dev} and {drums.device})")
+            if m - n - 1 < 0:
+                raise ValueError(f"signal of {m} samples is shorter than a {length} s clip")
+            ptrs[k, 0] = drums.data_ptr()
+            n_oth[k] = len(others)
+            lens[k] = m
+            alive[k] = (others, drums)
+            loaded = k + 1
+
+    load_rows(0, max(1, files_per_sync))
+    bank = torch.empty((N, 2, 96, T), dtype=torch.float32, device=dev)
     staged = torch.empty((chunk, 2, n), dtype=torch.float32, device=dev)
     row_off = torch.arange(chunk, dtype=torch.int64, device=dev) * (2 * n)       # start of staging row k, for the gate
     counts = torch.empty(chunk, dtype=torch.int32, device=dev)
+    fsync = max(1, files_per_sync)
+    # pinned crop tables: every group synchronises (the counts) before the next one refills `tab`; a missed file's single
+    # row goes through `tab1`, whose previous use lies at least one group synchronisation back
+    tab = torch.zeros((chunk, row_len), dtype=torch.int64, pin_memory=True)
+    tab1 = torch.zeros((1, row_len), dtype=torch.int64, pin_memory=True)
 
-    def stage(first_row: int, rows):
-        """rows: [(others, drums, start)] -> staging rows first_row ...; returns the tensors that must outlive the launch."""
-        tab = torch.zeros((len(rows), row_len), dtype=torch.int64, pin_memory=True)
-        tn = tab.numpy()
-        for k, (others, drums, st) in enumerate(rows):
-            tn[k, 0] = len(others)
-            tn[k, 1] = st
-            tn[k, 2] = drums.data_ptr()
-            for q, o in enumerate(others):
-                tn[k, 3 + q] = o.data_ptr()
-        dtab = tab.to(dev, non_blocking=True)
+    def stage(first_row: int, k0: int, starts, table=None):
+        """Staging rows first_row .. of the chunk's files k0 .. k0 + len(starts) - 1 cropped at `starts`."""
+        F = len(starts)
+        table = tab if table is None else table
+        tn = table.numpy()
+        tn[:F, 0] = n_oth[k0:k0 + F]
+        tn[:F, 1] = starts
+        tn[:F, 2:] = ptrs[k0:k0 + F]
+        dtab = table[:F].to(dev, non_blocking=True)
         with _ops.on_device(staged):
-            rc = L.zns_stage_crops_f32(dtab.data_ptr(), len(rows), MAX_OTHER, n, staged[first_row].data_ptr(),
-                                       _ops.stream_ptr(dev))
+            rc = L.zns_stage_crops_f32(dtab.data_ptr(), F, MAX_OTHER, n, staged[first_row].data_ptr(), _ops.stream_ptr(dev))
         _lib.check(rc, "zns_stage_crops_f32")
-        return tab, dtab, rows
+        return dtab
 
     pos = 0                       # next file whose crop start is unknown
-    keep = []
-    while pos < len(fps):
+    xqt_from = 0                  # first file whose rows have not gone through the XQT yet
+    group = fsync                 # files per synchronisation: doubles after a group without a miss, back to `files_per_sync` on one
+    randint = r.randint
+    while pos < N:
         base = pos - pos % chunk                                           # this chunk's first file = staging row 0
-        F = min(max(1, files_per_sync), len(fps) - pos, base + chunk - pos)
-        rows = []
-        state0 = r.getstate()                 # one snapshot per group (it is a 625-word tuple): a miss replays the draws before it
-        for i in range(pos, pos + F):
-            others, drums = signals(i)
-            rows.append((others, drums, r.randint(0, drums.numel() - n - 1)))
+        if pos == base and base > 0:
+            loaded = 0
         k0 = pos - base
-        keep.append(stage(k0, rows))
+        F = min(group, N - pos, chunk - k0)
+        load_rows(base, k0 + F)
+        state0 = r.getstate()                 # one snapshot per group (it is a 625-word tuple): a miss replays the draws before it
+        starts = [randint(0, lens[k] - n - 1) for k in range(k0, k0 + F)]
+        keep = stage(k0, k0, starts)
         with _ops.on_device(staged):
             rc = L.zns_rms_gate_f32(staged.data_ptr(), staged.data_ptr() + 4 * n, row_off[k0:].data_ptr(), F, n, None, None,
                                     counts.data_ptr(), _ops.stream_ptr(dev))
         _lib.check(rc, "zns_rms_gate_f32")
+        load_rows(base, k0 + F + min(2 * group, chunk))                    # the next group's files, while the GPU works
         got = counts[:F].tolist()                                          # the one synchronisation of this group
-        keep.clear()
-        for j in range(F):
-            if _first_pass(got[j], n_frames, lower_p, upper_p):
-                pos += 1
-                continue
+        miss = next((j for j in range(F) if not _first_pass(got[j], n_frames, lower_p, upper_p)), F)
+        pos += miss
+        if miss < F:
             # a miss: this file runs the reference's loop from its first draw; later files' draws start after its last
             r.setstate(state0)
-            for q in range(j):
-                r.randint(0, rows[q][1].numel() - n - 1)
-            others, drums = rows[j][0], rows[j][1]
+            for q in range(miss):
+                randint(0, lens[k0 + q] - n - 1)
+            others, drums = alive[k0 + miss]
             # the same float32 sum in the same (dict) order, from the vectors already on the device
             anchor, _ = mix_stems({**{f"other{q}": o for q, o in enumerate(others)}, "drums": drums})
             st = select_clip(anchor, drums, length, lower_p, upper_p, r)
-            keep.append(stage(pos - base, [(others, drums, st)]))
+            keep = stage(k0 + miss, k0 + miss, [st], tab1)
             pos += 1
-            break
-        for i in [i for i in resident if i < pos]:                         # files whose crop is final; speculated ones stay for the next group
-            del resident[i]
-        if pos - base == chunk or pos == len(fps):                         # the chunk's rows are final: transform them
-            k = pos - base
-            generate_XQT_batch(staged[:k].reshape(2 * k, n), 16000, mode, out=bank[base:pos].view(2 * k, 96, T),
-                               exact=exact or _yml_exact(ymldict))
+            group = fsync
+        else:
+            group = min(2 * group, chunk)
+        del keep
+        # rows that are final go through the XQT in spans of at least 96 files (192 clips: the fused kernel's batch), so that
+        # the transform of one span runs under the host's walk over the next
+        if pos - base == chunk or pos == N or pos - xqt_from >= 96:
+            k_lo, k_hi = xqt_from - base, pos - base
+            generate_XQT_batch(staged[k_lo:k_hi].reshape(2 * (k_hi - k_lo), n), 16000, mode,
+                               out=bank[xqt_from:pos].view(2 * (k_hi - k_lo), 96, T), exact=exact or _yml_exact(ymldict))
+            xqt_from = pos
     return bank
