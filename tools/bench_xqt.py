@@ -48,6 +48,9 @@ def cpu_oracle(n_clips=2):
 if __name__ == "__main__":
     if "--stages" in sys.argv:       # e.g. 7 = 3 | ZNS_XQT_SEPARATE, 11 = 3 | ZNS_XQT_FUSED, 19 = 3 | ZNS_XQT_EXACT
         STAGES = int(sys.argv[sys.argv.index("--stages") + 1])
+    if "--dbg" in sys.argv:          # phase-skipping bits of the fused kernel (WRONG RESULTS: timing bounds only), include/zns_test.h
+        from zeronotesamba_amd import _lib as _l
+        _l.check(_l.lib().zns_test_set_tuning(_l.ZNS_TUNE_XQT_DBG, int(sys.argv[sys.argv.index("--dbg") + 1])), "dbg")
     if "--plan" in sys.argv:         # decimation chains as digits, e.g. 223 (include/zns_test.h: ZNS_TUNE_XQT_PLAN)
         from zeronotesamba_amd import _lib as _l
         _l.check(_l.lib().zns_test_set_tuning(_l.ZNS_TUNE_XQT_PLAN, int(sys.argv[sys.argv.index("--plan") + 1])), "plan")

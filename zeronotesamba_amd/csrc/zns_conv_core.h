@@ -127,6 +127,7 @@ struct CoreArgs {
     int ncb;               // column blocks
     int dil, F;            // DILMAX > 0 only: tap spacing, number of frequency slots (weights indexed by (branch, f))
     int ipw;               // two-kind layout with EPI_SEP: consecutive samples per workgroup (>= 1; the grid shrinks accordingly)
+    int slot_major;        // DILMAX > 0: walk the (sample, slot) items slot-major (see conv_core)
     // split of the input-channel loop over `ks` workgroups (0 / 1: none): the configuration's CIN is then ONE part's channels,
     // `cin_full` the tensor's (x, packed weights); part k writes its raw sums to dx + k * N * COUT * H * T (EPI 1, no mask,
     // no unpool) and conv_split_finish_kernel adds the parts in order and applies the layer's epilogue
@@ -354,6 +355,18 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
     const int cinf = (!C::HET && A.cin_full > 0) ? A.cin_full : C::CIN;
     // several consecutive samples per workgroup (two-kind layout, host guarantees one block per sample then)
     const int ipw = (C::HET && C::EPI_SEP && A.ipw > 1) ? A.ipw : 1;
+    if constexpr (C::DILMAX > 0) {
+        // Frequency-domain launches: item = (sample, slot), and every item of a slot streams the SAME weight operator (cv4:
+        // 590 KB per slot, 113 MB per branch).  In item order a CU's L2 sees 24 different operators per sample and meets each
+        // again a whole sample pass (14 MB per XCD) later; walked slot-major in groups of eight slots -- block q -> slot
+        // 8 (q / 8 Ns) + q % 8, sample (q / 8) % Ns -- the eight XCDs (block id mod 8) each keep ONE operator in their 4 MB L2
+        // while the Ns samples pass through it.
+        if (ipw == 1 && A.slot_major && (A.F & 7) == 0) {
+            const int Ns = A.N / A.F, q = bid;
+            const int grp = q / (8 * Ns), r = q - grp * 8 * Ns;
+            bid = (r >> 3) * A.F + grp * 8 + (r & 7);
+        }
+    }
     int n = bid * ipw;
     const int nitems = ipw > 1 ? (A.N - n < ipw ? A.N - n : ipw) : 1;
     auto branch_of = [&](int nn) { return C::DILMAX ? nn / (A.B * A.F) : nn / A.B; };

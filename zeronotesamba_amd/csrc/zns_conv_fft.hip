@@ -1027,6 +1027,7 @@ static int run_fconv(const ConvArgs& a, const FftGeom& g, Ptr2 w, int transposed
             }
         }
     }
+    A.slot_major = tuning(ZNS_TUNE_IPW) == -2 ? 0 : 1;       // (-2: item order, for A/B timing)
     const long long blocks2 = A.ipw > 1 ? (long long)ceil_div(A.N, A.ipw)
                                         : (long long)A.N * A.ncb * (C::COUT / C::COB);
     const bool probe = probe_match(probe_kind, a.cin, a.cout, a.kh);
