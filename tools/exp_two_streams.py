@@ -22,6 +22,9 @@ P2 = _ops.StackParams.from_flat(m.anchor.stack_params() + m.postve.stack_params(
 G2 = _ops.StackParams.from_flat([torch.zeros_like(p) for p in m.anchor.stack_params() + m.postve.stack_params()], 2)
 
 
+SKEW = int(sys.argv[1]) if len(sys.argv) > 1 else 0       # cycles stream 1 sleeps before each pass (breaks the lockstep)
+
+
 def step_two_streams(stagger: bool):
     cur = torch.cuda.current_stream()
     outs = [None, None]
@@ -29,6 +32,8 @@ def step_two_streams(stagger: bool):
         streams[i].wait_stream(cur)
     for i in (0, 1):
         with torch.cuda.stream(streams[i]):
+            if i == 1 and SKEW:
+                torch.cuda._sleep(SKEW)
             outs[i] = _ops.stack_forward(xs[i], P[i], B, 0.1, 7 + i, True, ws_slot=2 + i)
     for i in (0, 1):
         cur.wait_stream(streams[i])
@@ -38,6 +43,8 @@ def step_two_streams(stagger: bool):
         streams[i].wait_stream(cur)
     for i in (0, 1):
         with torch.cuda.stream(streams[i]):
+            if i == 1 and SKEW:
+                torch.cuda._sleep(SKEW)
             e, acts, argm = outs[i]
             _ops.stack_backward(xs[i], P[i], B, acts, argm, e, demb[i * B:(i + 1) * B], None, 1 / 0.9, G[i], ws_slot=2 + i)
     for i in (0, 1):
