@@ -44,9 +44,11 @@ LAYER_GEOM = {"cv2": (64, 64, 7, 13, 96), "cv3": (64, 128, 5, 15, 32), "cv4": (1
 
 def window_length(layer: str, frames: int) -> int:
     """Overlap-save window of `layer` at this row length, as the library picks it (csrc/zns_conv_fft.hip: use_win128):
-    128 samples for cv3 / cv4 where that needs fewer frequency-windows per row than 64-sample windows, else 64."""
+    128 samples for cv2 / cv3 / cv4 where that needs fewer frequency-windows per row than 64-sample windows (cv2: rows of
+    one segment only), else 64."""
     kw = LAYER_GEOM[layer][3]
-    if layer in ("cv3", "cv4") and 2 * -(-frames // (129 - kw)) < -(-frames // (65 - kw)):
+    n128 = -(-frames // (129 - kw))
+    if layer in ("cv2", "cv3", "cv4") and 2 * n128 < -(-frames // (65 - kw)) and not (layer == "cv2" and n128 > 6):
         return 128
     return 64
 

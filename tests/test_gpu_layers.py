@@ -375,11 +375,11 @@ def test_k_split_cv7_cv8_equal_the_unsplit_kernels(li, T):
         assert (d - d0).abs().max().item() <= 1e-5 * d0.abs().max().item()
 
 
-@pytest.mark.parametrize("li", [2, 3])
+@pytest.mark.parametrize("li", [1, 2, 3])
 @pytest.mark.parametrize("T,nbr,B", [(512, 2, 2), (313, 2, 1), (626, 1, 1), (1876, 1, 1), (32, 1, 2), (45, 2, 1), (115, 1, 1),
                                      (229, 1, 3), (343, 2, 1), (700, 1, 1)])
 def test_window_128_equals_window_64(li, T, nbr, B):
-    """cv3 / cv4 on 128-point overlap-save windows (zns_conv_fft.hip: use_win128, FF3w / FF4w / FD3w tiles, 192 slots)
+    """cv2 / cv3 / cv4 on 128-point overlap-save windows (zns_conv_fft.hip: use_win128, FF2w / FF3w / FF4w / FD3w tiles, 192 slots)
     against the same layer on 64-point windows: forward with pooling / dropout / arg-max, backward-data with mask and
     unpool, backward-weights and bias gradient, with the spectra handed from call to call as the trainer does -- 2e-5 of the
     result's scale (two summation orders of the same fp32 products).  Lengths: the benchmarked rows, one window (32, 45),

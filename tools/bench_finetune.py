@@ -12,6 +12,9 @@ from zeronotesamba_amd.epochs import bce_loss
 from zeronotesamba_amd.models.models import Down_CNN
 from zeronotesamba_amd.optim import Adam
 
+if "--win128" in sys.argv:       # cv2 / cv3 / cv4 window length: 1 force 128-point, -1 force 64-point (include/zns_test.h)
+    from zeronotesamba_amd import _lib
+    _lib.check(_lib.lib().zns_test_set_tuning(_lib.ZNS_TUNE_WIN128, int(sys.argv[sys.argv.index("--win128") + 1])), "tuning")
 dev = torch.device("cuda", 0)
 T = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 1876
 torch.manual_seed(0)

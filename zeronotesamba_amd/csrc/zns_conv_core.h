@@ -1031,6 +1031,10 @@ static int wg_pick_ks(const ConvArgs& a, int* tiles_total, int* tps) {
         const long long wgs = (long long)base * ks;
         const long long rounds = (wgs + cus - 1) / cus;
         double eff = (double)wgs / (double)(rounds * cus) * ((double)total / ((double)ks * per));
+        // a workgroup's first K-tile load, its partial-slab store and the reducer's extra read cost about two K-tiles of time:
+        // without this term a short K axis (the batch-of-one fine-tune step on 192 slots: 54 tiles) was split 54 ways for a
+        // last 2 % of grid fill -- one tile per workgroup, a 2.4 GB slab, 0.7 ms of reduce
+        eff *= (double)per / ((double)per + 2.0);
         if (wgs < cus) eff *= 0.5;                               // do not leave CUs without a workgroup
         if (eff > best_eff + 0.02 || (eff > best_eff - 1e-9 && wgs >= 2LL * cus && (long long)base * best_ks < 2LL * cus)) {
             best_eff = eff;

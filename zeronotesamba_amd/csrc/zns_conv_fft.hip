@@ -765,6 +765,15 @@ using FD4wa = FF4wa;
 // of (1 x 5), 22.79 for one wave of (2 x 5), 22.84 for two waves of (2 x 3); cv3 forward as two waves of (2 x 5): 22.88; cv4
 // as two waves of (2 x 5) (352 registers, one wave per SIMD): 23.08.
 using FD3w = ConvCfg<128, 64, 1, 5, 1, 1, 1, 3, 2, 1, 2, 8, 1, 1, FDIL128>;
+// cv2 on 128-point windows, one-segment rows only (use_win128): T = 313 -> 3 x 64 frequency-windows against 7 x 32, T = 626
+// -> 6 x 64 against 13 x 32 in two segments (the step 30.1 -> 28.7 ms); T = 512 is a tie and stays on 64.  P = 96 NB = 288 /
+// 576: four waves of (1 x 3) over 192-column blocks (P = 288: the second block half dead, its tiles skipped).  Measured per
+// step at T = 313: 15.89 ms, against 16.01 for two-wave 96-column blocks, 15.99 for six waves over 288 columns, 16.02 for
+// three waves of (2 x 3); 64-point windows: 16.0.  Long rows (the 30 s fine-tune clips, batch of one) stay on 64-point
+// windows: with two samples per launch the doubled operators (weight pack, slab reduce) cost more than the GEMMs gain
+// (6.85 against 6.72 ms per step).
+using FF2w = ConvCfg<64, 64, 1, 7, 1, 1, 1, 3, 2, 1, 2, 8, 1, 1, FDIL128>;
+using FD2w = FF2w;
 using FD3wa = ConvCfg<128, 64, 1, 5, 1, 1, 1, 3, 2, 1, 1, 8, 1, 1, FDIL128>;
 //                 CIN COUT KH KW(taps) H  MT NS WMW WQ R DILMAX WCI
 using FW2 = WgCfg<64, 64, 1, 7, 1, 1, 7, 2, 1, 1, FDILW, 2, 32>;
@@ -795,17 +804,19 @@ static int fft_layer_of(const ConvArgs& a) {
     return -1;
 }
 
-// 128-point windows for cv3 / cv4 wherever they need fewer frequency-windows per row than 64-point ones (2 per window
+// 128-point windows for cv2 / cv3 / cv4 wherever they need fewer frequency-windows per row than 64-point ones (2 per window
 // against 1: T = 512: 2 x 5 against 11; the reference's T = 313: 2 x 3 against 7; rows under ~100 frames stay on 64).  A
 // function of (layer, T) alone, never of the batch: a clip's sums must not depend on the batch it is in.
 // zns_test_set_tuning(ZNS_TUNE_WIN128, 1 / -1) forces / forbids it (tests compare the two).
 static bool use_win128(const ConvArgs& a) {
     const int l = fft_layer_of(a);
-    if (l != 3 && l != 4) return false;
+    if (l != 2 && l != 3 && l != 4) return false;
     const int m = tuning(ZNS_TUNE_WIN128);
     if (m < 0) return false;
     if (m > 0) return true;
-    return 2 * ceil_div(a.T, 129 - a.kw) < ceil_div(a.T, 65 - a.kw);
+    const int n128 = ceil_div(a.T, 129 - a.kw);
+    if (l == 2 && n128 > FDIL128) return false;          // cv2: one-segment rows only (see FF2w)
+    return 2 * n128 < ceil_div(a.T, 65 - a.kw);
 }
 
 static FftGeom geom(const ConvArgs& a) {
@@ -1155,6 +1166,9 @@ template <class Fn>
 static int with_cfg(const ConvArgs& a, int transposed, Fn&& f) {
     switch (fft_layer_of(a)) {
         case 2:
+            if (use_win128(a)) {
+                return transposed ? f(cfg_tag<FD2w>{}) : f(cfg_tag<FF2w>{});
+            }
             // (a tie -- T = 313: P = 672, 768 padded columns either way -- stays with the 256-column blocks: 993 us against 1006)
             if (use_narrow<FF2, FF2a>(a)) return transposed ? f(cfg_tag<FD2a>{}) : f(cfg_tag<FF2a>{});
             return transposed ? f(cfg_tag<FD2>{}) : f(cfg_tag<FF2>{});
