@@ -774,7 +774,12 @@ using FD3w = ConvCfg<128, 64, 1, 5, 1, 1, 1, 3, 2, 1, 2, 8, 1, 1, FDIL128>;
 // (6.85 against 6.72 ms per step).
 using FF2w = ConvCfg<64, 64, 1, 7, 1, 1, 1, 3, 2, 1, 2, 8, 1, 1, FDIL128>;
 using FD2w = FF2w;
+// P = 288 (T = 313): 2 x 9 tiles do not split evenly over four waves; 320-column blocks of four waves x (1 x 5) give the waves
+// 5 / 5 / 4 / 4 live tiles (the tenth column tile is dead) instead of 3 / 3 / 3 / 3 + 3 / 3 / 0 / 0 in two 192-column blocks
+using FF2wb = ConvCfg<64, 64, 1, 7, 1, 1, 1, 5, 2, 1, 2, 8, 1, 1, FDIL128>;
+using FD2wb = FF2wb;
 using FD3wa = ConvCfg<128, 64, 1, 5, 1, 1, 1, 3, 2, 1, 1, 8, 1, 1, FDIL128>;
+using FD3wX = ConvCfg<128, 64, 1, 5, 1, 1, 1, 2, 2, 1, 2, 8, 1, 1, FDIL128>;     // EXPERIMENT: P = 96 as four waves of 2 / 2 / 1 / 1 tiles
 //                 CIN COUT KH KW(taps) H  MT NS WMW WQ R DILMAX WCI
 using FW2 = WgCfg<64, 64, 1, 7, 1, 1, 7, 2, 1, 1, FDILW, 2, 32>;
 using FW3 = WgCfg<64, 128, 1, 5, 1, 1, 5, 4, 1, 1, FDILW, 2, 32>;
@@ -1167,13 +1172,16 @@ static int with_cfg(const ConvArgs& a, int transposed, Fn&& f) {
     switch (fft_layer_of(a)) {
         case 2:
             if (use_win128(a)) {
-                return transposed ? f(cfg_tag<FD2w>{}) : f(cfg_tag<FF2w>{});
+                // (T = 313 per step: 15.43-15.49 ms with the 320-column blocks against 15.81-15.87 with 192-column ones)
+                if (use_narrow<FF2wb, FF2w>(a)) return transposed ? f(cfg_tag<FD2w>{}) : f(cfg_tag<FF2w>{});
+                return transposed ? f(cfg_tag<FD2wb>{}) : f(cfg_tag<FF2wb>{});
             }
             // (a tie -- T = 313: P = 672, 768 padded columns either way -- stays with the 256-column blocks: 993 us against 1006)
             if (use_narrow<FF2, FF2a>(a)) return transposed ? f(cfg_tag<FD2a>{}) : f(cfg_tag<FF2a>{});
             return transposed ? f(cfg_tag<FD2>{}) : f(cfg_tag<FF2>{});
         case 3:
             if (use_win128(a)) {
+                if (transposed && tuning(ZNS_TUNE_IPW) == 99) return f(cfg_tag<FD3wX>{});
                 if (transposed) return use_narrow<FD3w, FD3wa>(a) ? f(cfg_tag<FD3wa>{}) : f(cfg_tag<FD3w>{});
                 return use_narrow<FF3w, FF3wa>(a) ? f(cfg_tag<FF3wa>{}) : f(cfg_tag<FF3w>{});
             }
