@@ -778,8 +778,9 @@ using FD2w = FF2w;
 // 5 / 5 / 4 / 4 live tiles (the tenth column tile is dead) instead of 3 / 3 / 3 / 3 + 3 / 3 / 0 / 0 in two 192-column blocks
 using FF2wb = ConvCfg<64, 64, 1, 7, 1, 1, 1, 5, 2, 1, 2, 8, 1, 1, FDIL128>;
 using FD2wb = FF2wb;
-using FD3wa = ConvCfg<128, 64, 1, 5, 1, 1, 1, 3, 2, 1, 1, 8, 1, 1, FDIL128>;
-using FD3wX = ConvCfg<128, 64, 1, 5, 1, 1, 1, 2, 2, 1, 2, 8, 1, 1, FDIL128>;     // EXPERIMENT: P = 96 as four waves of 2 / 2 / 1 / 1 tiles
+// P = 96 (T = 313: 2 x 3 tiles): four waves over 128 columns with 2 / 2 / 1 / 1 live tiles (fourth column tile dead) -- T = 313
+// per step 15.40-15.44 ms against 15.47-15.49 for two-wave workgroups of (1 x 3)
+using FD3wa = ConvCfg<128, 64, 1, 5, 1, 1, 1, 2, 2, 1, 2, 8, 1, 1, FDIL128>;
 //                 CIN COUT KH KW(taps) H  MT NS WMW WQ R DILMAX WCI
 using FW2 = WgCfg<64, 64, 1, 7, 1, 1, 7, 2, 1, 1, FDILW, 2, 32>;
 using FW3 = WgCfg<64, 128, 1, 5, 1, 1, 5, 4, 1, 1, FDILW, 2, 32>;
@@ -1181,7 +1182,6 @@ static int with_cfg(const ConvArgs& a, int transposed, Fn&& f) {
             return transposed ? f(cfg_tag<FD2>{}) : f(cfg_tag<FF2>{});
         case 3:
             if (use_win128(a)) {
-                if (transposed && tuning(ZNS_TUNE_IPW) == 99) return f(cfg_tag<FD3wX>{});
                 if (transposed) return use_narrow<FD3w, FD3wa>(a) ? f(cfg_tag<FD3wa>{}) : f(cfg_tag<FD3w>{});
                 return use_narrow<FF3w, FF3wa>(a) ? f(cfg_tag<FF3wa>{}) : f(cfg_tag<FF3w>{});
             }
