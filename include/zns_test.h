@@ -31,7 +31,8 @@ enum {
     ZNS_TUNE_XQT_CHUNKS,      /* fused generate_XQT kernel: runs a clip is cut into, 0 = default */
     ZNS_TUNE_XQT_DBG,         /* fused kernel: phase-skipping bits (WRONG RESULTS: timing diagnosis only) */
     ZNS_TUNE_XQT_STAMPS,      /* fused kernel: record s_memtime stamps of workgroup 0 (zns_xqt_debug_stamps) */
-    ZNS_TUNE_WIN128,          /* cv3 / cv4 spectral window: 0 by the launcher's rule, 1 force 128-point, -1 force 64-point */
+    ZNS_TUNE_WIN128,          /* cv2 / cv3 / cv4 spectral window: 0 by the launcher's rule, 1 force 128-point, -1 force 64-point */
+    ZNS_TUNE_XQT_WAVES16,     /* fused generate_XQT kernel: 0 = 16 waves (two filter waves per SIMD, default), -1 = the 12-wave layout */
     ZNS_TUNE_COUNT
 };
 int zns_test_set_tuning(int key, int value);

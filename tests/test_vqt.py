@@ -472,6 +472,14 @@ def test_fused_kernel_equals_the_per_stage_launches_bitwise(n, clips):
     sep = generate_XQT_batch(y, 16000, "vqt", stages=3 | _lib.ZNS_XQT_SEPARATE)
     fus = generate_XQT_batch(y, 16000, "vqt", stages=3 | _lib.ZNS_XQT_FUSED)
     assert torch.equal(sep, fus), (n, clips, (sep - fus).abs().max().item())
+    # both wave layouts of the fused kernel (12 waves: one filter wave per SIMD; 16 waves: two, each a row tile of its octaves)
+    L = _lib.lib()
+    try:
+        assert L.zns_test_set_tuning(_lib.ZNS_TUNE_XQT_WAVES16, -1) == 0          # (the default, above, is the 16-wave layout)
+        fus12 = generate_XQT_batch(y, 16000, "vqt", stages=3 | _lib.ZNS_XQT_FUSED)
+    finally:
+        L.zns_test_set_tuning(_lib.ZNS_TUNE_XQT_WAVES16, 0)
+    assert torch.equal(sep, fus12), (n, clips, (sep - fus12).abs().max().item())
     if clips <= 5:
         ref = vqt_ref.generate_XQT(y[clips - 1].cpu().numpy(), 16000, "vqt")              # and both against the oracle
         assert_matches_oracle(fus[clips - 1].cpu().numpy(), ref, "default")

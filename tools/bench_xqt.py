@@ -51,6 +51,9 @@ if __name__ == "__main__":
     if "--dbg" in sys.argv:          # phase-skipping bits of the fused kernel (WRONG RESULTS: timing bounds only), include/zns_test.h
         from zeronotesamba_amd import _lib as _l
         _l.check(_l.lib().zns_test_set_tuning(_l.ZNS_TUNE_XQT_DBG, int(sys.argv[sys.argv.index("--dbg") + 1])), "dbg")
+    if "--waves16" in sys.argv:      # the fused kernel's wave layout: 0 = 16 waves (default), -1 = 12 waves (include/zns_test.h)
+        from zeronotesamba_amd import _lib as _l
+        _l.check(_l.lib().zns_test_set_tuning(_l.ZNS_TUNE_XQT_WAVES16, int(sys.argv[sys.argv.index("--waves16") + 1])), "waves16")
     if "--plan" in sys.argv:         # decimation chains as digits, e.g. 223 (include/zns_test.h: ZNS_TUNE_XQT_PLAN)
         from zeronotesamba_amd import _lib as _l
         _l.check(_l.lib().zns_test_set_tuning(_l.ZNS_TUNE_XQT_PLAN, int(sys.argv[sys.argv.index("--plan") + 1])), "plan")

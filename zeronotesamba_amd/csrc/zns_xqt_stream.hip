@@ -1,7 +1,9 @@
 // generate_XQT (vqt) in ONE launch: xqt_stream_kernel.  input_rep.py:41-54 -> librosa.vqt, see zns_xqt.hip for the arithmetic.
 //
 // The per-stage launches move every pyramid level to HBM and back: 13-14 GB for 4096 ten-second clips whose algorithmic
-// traffic is 3.6 GB (2.6 in, 1.0 out).  Here a persistent 768-thread workgroup STREAMS through its clips in time order,
+// traffic is 3.6 GB (2.6 in, 1.0 out).  Here a persistent workgroup (1024 threads: xqt_stream16_kernel, the default since
+// round 5 -- eight pyramid waves + eight filter waves, see there; 768 threads: xqt_stream_kernel, the round-4 layout with four
+// filter waves described below, kept as the second implementation the tests compare) STREAMS through its clips in time order,
 // 4096 level-0 samples (16 frames) per step, ONE barrier per step, and no pyramid sample ever leaves LDS:
 //   * waves 0..7, the pyramid: thread = (level j, 8 consecutive outputs).  EVERY level advances in EVERY step, level j one
 //     step behind level j - 1 (a systolic pipeline, so nothing is recomputed and all eight waves carry the same load):
@@ -517,6 +519,80 @@ __device__ __forceinline__ void filter_role(const Args& P, float* __restrict__ l
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 16-wave variant
+// TWO filter waves per SIMD (waves 8 + s and 12 + s sit on SIMD s): wave (WV, HALF) multiplies row tile HALF of octave WV
+// (32 of its 64 MFMAs) and row tile HALF of one short octave.  Why: with one filter wave per SIMD its chain -- stage the tile
+// image, 80 MFMAs, log epilogue, stores -- is the critical path of a step (phase-skipping bounds, DESIGN.md section 5:
+// without the multiplies 2.08 of 2.88 ms per 4096 clips, without the staging 2.52); two waves run the two halves of that
+// chain side by side and cover each other's LDS and store latencies.  Both stage the octave's image for themselves (a
+// barrier between a staging wave and a multiplying wave costs more than the 8 KB of LDS traffic).
+//   wave (0, 0): octave 0 rt 0 + octave 7 rt 0      wave (0, 1): octave 0 rt 1 + octave 4 rt 1
+//   wave (1, h): octave 1 rt h + octave 6 rt h      wave (2, h): octave 2 rt h + octave 5 rt h
+//   wave (3, 0): octave 3 rt 0 + octave 4 rt 0      wave (3, 1): octave 3 rt 1 + octave 7 rt 1
+constexpr int NTHR2 = 1024;
+__host__ __device__ constexpr int S2_(int wv, int half) { return wv == 0 ? (half ? 4 : 7) : wv == 1 ? 6 : wv == 2 ? 5 : (half ? 7 : 4); }
+__host__ __device__ constexpr int STG2_SLOT(int wv, int half) { return STG_(wv) + STG_(S2_(wv, half)); }
+__host__ __device__ constexpr int STG2_OFF(int wv, int half) {
+    int o = 0;
+    for (int w = 0; w < 4; ++w)
+        for (int h = 0; h < 2; ++h) {
+            if (w == wv && h == half) return o;
+            o += STG2_SLOT(w, h);
+        }
+    return o;
+}
+constexpr int STG2_FLOATS = STG2_OFF(3, 1) + STG2_SLOT(3, 1);
+constexpr int LDS_FLOATS2 = WIN_FLOATS + STG2_FLOATS;
+static_assert(LDS_FLOATS2 * 4 <= 160 * 1024, "LDS (16-wave variant)");
+
+template <int WV, int HALF>
+__device__ __forceinline__ void filter_role2(const Args& P, float* __restrict__ lds, int b, int nmine, int steps) {
+    const int lane = threadIdx.x & 63;
+    constexpr int S2 = S2_(WV, HALF);
+    constexpr int RTM = HALF ? 2 : 1;
+    float* __restrict__ stgB = lds + WIN_FLOATS + STG2_OFF(WV, HALF);
+    float* __restrict__ stgS = stgB + STG_(WV);
+    float a[32], c[NFFT_(S2) / 4];
+    load_operand<32>(P.fira16 + P.offa16[WV] + HALF * 32 * 64, lane, a);
+    load_operand<NFFT_(S2) / 4>(P.fira16 + P.offa16[S2] + HALF * (NFFT_(S2) / 4) * 64, lane, c);
+    Oct<WV> OB; Oct<S2> OS;
+    OB.init(P, lane, b); OS.init(P, lane, b);
+    if (!(P.dbg & 64)) __builtin_amdgcn_s_setprio(3);
+    for (int s = 0; s < steps; ++s) {
+        const int par = s & 1;
+        OB.begin(P, nmine); OS.begin(P, nmine);
+        const bool stage = !(P.dbg & 4);
+        float4 vb[Oct<WV>::NIT], vs[Oct<S2>::NIT];
+        if (stage && OB.tile && !OB.edge) OB.stage_load(lds, par, lane, vb);
+        if (stage && OS.tile && !OS.edge) OS.stage_load(lds, par, lane, vs);
+        if (stage && OB.tile) { if (OB.edge) stage_edge<WV>(P.wav + (long long)OB.clip * P.n, P.len[WV], OB.worig(P), OB.Ff, lds, stgB, par, lane); else OB.stage_store(stgB, lane, vb); }
+        if (stage && OS.tile) { if (OS.edge) stage_edge<S2>(P.wav + (long long)OS.clip * P.n, P.len[S2], OS.worig(P), OS.Ff, lds, stgS, par, lane); else OS.stage_store(stgS, lane, vs); }
+        if (OB.tile) octave_mma<WV, RTM>(P, OB, stgB, lane, a, a);
+        if (OS.tile) octave_mma<S2, RTM>(P, OS, stgS, lane, c, c);
+        OB.advance(P, b); OS.advance(P, b);
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(NTHR2) xqt_stream16_kernel(Args P) {
+    extern __shared__ __attribute__((aligned(16))) float sq_lds[];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int nmine = (P.nitems - b + P.G - 1) / P.G;
+    const int steps = nmine * P.K + LAG;
+    for (int i = tid; i < LDS_FLOATS2 / 4; i += NTHR2) reinterpret_cast<float4*>(sq_lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (wv < NPYR / 64) pyramid_role(P, sq_lds, b, nmine, steps);
+    else if (wv == 8) filter_role2<0, 0>(P, sq_lds, b, nmine, steps);
+    else if (wv == 9) filter_role2<1, 0>(P, sq_lds, b, nmine, steps);
+    else if (wv == 10) filter_role2<2, 0>(P, sq_lds, b, nmine, steps);
+    else if (wv == 11) filter_role2<3, 0>(P, sq_lds, b, nmine, steps);
+    else if (wv == 12) filter_role2<0, 1>(P, sq_lds, b, nmine, steps);
+    else if (wv == 13) filter_role2<1, 1>(P, sq_lds, b, nmine, steps);
+    else if (wv == 14) filter_role2<2, 1>(P, sq_lds, b, nmine, steps);
+    else filter_role2<3, 1>(P, sq_lds, b, nmine, steps);
+}
+
 __global__ void __launch_bounds__(NTHR) xqt_stream_kernel(Args P) {
     extern __shared__ __attribute__((aligned(16))) float sq_lds[];
     const int tid = threadIdx.x, b = blockIdx.x;
@@ -586,13 +662,18 @@ int xqt_stream_launch(const Bank* b, const float* wav, int n_clips, int n_sample
         A.stamps = sb;
         g_last_stamps = sb;
     }
-    const size_t lds = (size_t)LDS_FLOATS * sizeof(float);
     static bool lds_set[ZNS_MAX_DEVICES] = {};
     if (!lds_set[current_device_slot()]) {
         ZNS_HIP(hipFuncSetAttribute((const void*)xqt_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ZNS_HIP(hipFuncSetAttribute((const void*)xqt_stream16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         lds_set[current_device_slot()] = true;
     }
-    hipLaunchKernelGGL(xqt_stream_kernel, dim3((unsigned)A.G), dim3(NTHR), lds, st, A);
+    // 16 waves (two filter waves per SIMD) unless a test asks for the 12-wave layout or the cycle stamps (12-wave only) are on:
+    // same bits; per 4096 / 2048 / 1024 / 192 clips 2.77 / 1.26 / 0.68 / 0.182 ms against 2.87 / 1.41 / 0.76 / 0.193
+    if (tuning(ZNS_TUNE_XQT_WAVES16) >= 0 && !A.stamps)
+        hipLaunchKernelGGL(xqt_stream16_kernel, dim3((unsigned)A.G), dim3(NTHR2), (size_t)LDS_FLOATS2 * sizeof(float), st, A);
+    else
+        hipLaunchKernelGGL(xqt_stream_kernel, dim3((unsigned)A.G), dim3(NTHR), (size_t)LDS_FLOATS * sizeof(float), st, A);
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
 }
