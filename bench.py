@@ -87,7 +87,7 @@ PROBE = dict(kind=0, cin=128, cout=128, kh=9, name="conv_core<spectral cv4 forwa
              # counts the 128-B requests of 16-byte loads as 64 B) + WRITE_SIZE of this kernel's row in PROBE_PMC_FILE.
              # tests/test_bench_contract.py fails when the two drift apart (a new profile set must update both).
              # (1.233 GB against 1.232 GB algorithmic: 503 MB of input spectrum + 503 MB of output + 226 MB of operators)
-             traffic=(2 * 356501 + 491520) * 1024.0,
+             traffic=(2 * 356483 + 491520) * 1024.0,
              traffic_source="constant from separate rocprofv3 --pmc passes (profiles/r05_pmc_summary.csv), 2 x FETCH_SIZE + WRITE_SIZE; not measured by this run")
 PROBE_PMC_FILE = "profiles/r05_pmc_summary.csv"
 PROBE_PMC_KERNEL = "conv_core<ConvCfg<128, 128, 1, 9, 1, 1, 1, 5, 4, 1, 1, 4,"      # cv4 forward / backward-data on 128-point windows: 4 waves x (1 x 5)
