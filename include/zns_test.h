@@ -24,7 +24,8 @@ int zns_set_impl(int impl);
  * KSPLIT: -1) is the product behaviour.  zns_test_set_tuning returns ZNS_OK or ZNS_ERR_ARG (unknown key). */
 enum {
     ZNS_TUNE_KSPLIT = 0,      /* cv7 / cv8 input-channel split: -1 by the rule of T (default), 0 never, 2 / 4 / 8 forced */
-    ZNS_TUNE_IPW,             /* two-kind spectral layout: (sample, slot) items per workgroup, 0 = chosen by the launcher */
+    ZNS_TUNE_IPW,             /* two-kind spectral layout: (sample, slot) items per workgroup, 0 = chosen by the launcher;
+                               * -2: spectral GEMM launches walk their items in item order instead of slot-major (A/B timing) */
     ZNS_TUNE_XQT_PLAN,        /* per-stage pyramid: chain lengths as decimal digits (223 = chains of 2, 2, 3 levels), 0 = default */
     ZNS_TUNE_XQT_LDS_PAD,     /* exact pyramid: pad the chain kernel's LDS to this many KiB (caps occupancy) */
     ZNS_TUNE_XQT_TPW,         /* per-stage filter bank: tiles per wave, 0 = default */

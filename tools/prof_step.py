@@ -14,10 +14,14 @@ ap.add_argument("--steps", type=int, default=4)
 ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--win128", type=int, default=0, help="cv3 / cv4 window length: 0 library rule, 1 force 128-point, -1 force 64-point")
 ap.add_argument("--ipw", type=int, default=0, help="ZNS_TUNE_IPW (experiments)")
+ap.add_argument("--ksplit", type=int, default=-1, help="cv7 / cv8 input-channel split: -1 rule, 0 off, 2 / 4 / 8")
 a = ap.parse_args()
 if a.ipw:
     from zeronotesamba_amd import _lib
     _lib.check(_lib.lib().zns_test_set_tuning(_lib.ZNS_TUNE_IPW, a.ipw), "tuning")
+if a.ksplit != -1:
+    from zeronotesamba_amd import _lib
+    _lib.check(_lib.lib().zns_test_set_tuning(_lib.ZNS_TUNE_KSPLIT, a.ksplit), "tuning")
 if a.win128:
     from zeronotesamba_amd import _lib
     _lib.check(_lib.lib().zns_test_set_tuning(_lib.ZNS_TUNE_WIN128, a.win128), "tuning")
