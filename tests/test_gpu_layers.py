@@ -427,3 +427,45 @@ def test_window_128_equals_window_64(li, T, nbr, B):
         near(u, v, "backward-weights")
     for u, v in zip(c[4], a[4]):
         near(u, v, "bias gradient")
+
+
+@pytest.mark.parametrize("win", [-1, 1])
+@pytest.mark.parametrize("li,T,nbr,B", [(1, 313, 2, 1), (2, 512, 1, 2), (3, 229, 2, 1), (4, 313, 1, 2), (5, 512, 2, 1), (2, 45, 1, 1)])
+def test_nothing_reads_the_unused_third_plane_of_frequency_slot_0(li, T, nbr, B, win):
+    """Frequency slot 0 carries the two real bins (DC, Nyquist) in its first two Karatsuba planes; there is no third product,
+    and the GEMM launches skip that (sample, slot 2) item (zns_conv_core.h).  Its output plane and its partial slab therefore
+    hold whatever the workspace held: with the workspace poisoned (all-ones bytes = NaN) every result must be bit-identical
+    to a run on a zeroed workspace, on both window lengths."""
+    _lib, _ops = _mods()
+    L = _lib.lib()
+    name, cin, cout, kh, kw, pool = _ops.LAYERS[li]
+    H = _ops.H_IN[li]
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(31 * li + T)
+    x = torch.randn((nbr * B, cin, H, T), generator=g).clamp_(min=0).to(dev)
+    w = [(torch.randn((cout, cin, kh, kw), generator=g) / (cin * kh * kw) ** 0.5).to(dev) for _ in range(nbr)]
+    b = [(torch.randn((cout,), generator=g) * 0.1).to(dev) for _ in range(nbr)]
+    dz = torch.randn((nbr * B, cout, H, T), generator=g).to(dev)
+    pp = _ops.LAYERS[li - 1][5]
+    am_prev = torch.randint(0, pp, (nbr * B, cin, H, T), generator=g, dtype=torch.uint8).to(dev) if pp > 1 else None
+    outs = []
+    try:
+        assert L.zns_test_set_tuning(_lib.ZNS_TUNE_WIN128, win) == 0
+        for poison in (0, 255):
+            ws = _ops.workspace(_ops.conv_workspace_bytes(nbr, B, T), dev, 0)
+            ws.fill_(poison)
+            y, am, spec = _ops.conv_fwd(li, nbr, B, T, x, w, b, 0.1, 77, True, ws)
+            dw = [torch.zeros_like(t) for t in w]
+            db = [torch.zeros_like(t) for t in b]
+            ws.fill_(poison)
+            _ops.conv_wgrad(li, nbr, B, T, dz, x, dw, db, False, ws, xspec=spec)
+            ws.fill_(poison)
+            dx = _ops.conv_dgrad(li, nbr, B, T, dz, w, x, 1.0 / 0.9, am_prev, pp, ws)
+            torch.cuda.synchronize()
+            outs.append((y.clone(), dx.clone(), [t.clone() for t in dw], [t.clone() for t in db]))
+    finally:
+        L.zns_test_set_tuning(_lib.ZNS_TUNE_WIN128, 0)
+    a, c = outs
+    assert torch.isfinite(c[0]).all() and torch.isfinite(c[1]).all()
+    assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]), name
+    assert all(torch.equal(u, v) for u, v in zip(a[2], c[2])) and all(torch.equal(u, v) for u, v in zip(a[3], c[3])), name

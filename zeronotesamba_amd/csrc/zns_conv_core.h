@@ -368,6 +368,11 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
         }
     }
     int n = bid * ipw;
+    if constexpr (C::DILMAX > 0) {
+        // slot 2 = the third Karatsuba part of frequency slot 0, which holds the two REAL bins (DC, Nyquist): there is no such
+        // product, nobody reads its output plane
+        if (ipw == 1 && n % A.F == 2) return;
+    }
     const int nitems = ipw > 1 ? (A.N - n < ipw ? A.N - n : ipw) : 1;
     auto branch_of = [&](int nn) { return C::DILMAX ? nn / (A.B * A.F) : nn / A.B; };
     const int br = branch_of(n);
@@ -839,6 +844,9 @@ __global__ void __launch_bounds__(C::NT, C::WPE) wgrad_core(WgArgs A) {
     const int cob = bid % (C::COUT / C::COB); bid /= (C::COUT / C::COB);
     const int ks = bid % A.KS;
     const int br = bid / A.KS;
+    if constexpr (C::DILMAX > 0) {
+        if (br % A.F == 2) return;       // (frequency slot 0 has no third Karatsuba part: see conv_core)
+    }
 
     const int q0 = qg * C::G;
     const int r0 = q0 / C::KW;
