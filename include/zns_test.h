@@ -34,6 +34,7 @@ enum {
     ZNS_TUNE_XQT_STAMPS,      /* fused kernel: record s_memtime stamps of workgroup 0 (zns_xqt_debug_stamps) */
     ZNS_TUNE_WIN128,          /* cv2 / cv3 / cv4 spectral window: 0 by the launcher's rule, 1 force 128-point, -1 force 64-point */
     ZNS_TUNE_XQT_WAVES16,     /* fused generate_XQT kernel: 0 = 16 waves (two filter waves per SIMD, default), -1 = the 12-wave layout */
+    ZNS_TUNE_ONE_ROW_DIRECT,  /* cv7 / cv8: 0 = frequency domain (one GEMM per branch and slot, default), 1 = the direct kernels */
     ZNS_TUNE_COUNT
 };
 int zns_test_set_tuning(int key, int value);

@@ -64,7 +64,10 @@ RAGGED = [(1, 31, 2, 1), (1, 32, 1, 3), (2, 33, 2, 1), (3, 45, 1, 1), (4, 97, 2,
           (1, 34, 1, 2), (2, 39, 2, 1), (3, 66, 2, 1), (4, 47, 1, 1), (5, 121, 2, 1), (2, 627, 1, 1),
           # cv1 alone (its own matrix-pipe kernels: a K = 34 GEMM per image row forward, taps as a GEMM over pixels backward):
           # every residue of T mod 4, rows shorter than one 32-column group, the reference's 313-frame crop, odd batches
-          (0, 31, 1, 1), (0, 34, 2, 3), (0, 39, 1, 3), (0, 313, 2, 1), (0, 627, 1, 1), (0, 33, 1, 1)]
+          (0, 31, 1, 1), (0, 34, 2, 3), (0, 39, 1, 3), (0, 313, 2, 1), (0, 627, 1, 1), (0, 33, 1, 1),
+          # cv7 / cv8 in the frequency domain (one GEMM per branch and slot, the batch as rows): odd batches and lengths (P = B * NBT
+          # not a multiple of 4: 4-byte staging, scalar stores), one window, two column blocks (P > 224), a 60 s clip
+          (6, 33, 1, 3), (7, 45, 2, 1), (6, 627, 1, 2), (7, 313, 2, 5), (6, 512, 2, 3), (7, 626, 1, 16), (6, 3751, 1, 1), (7, 41, 1, 1)]
 
 
 @pytest.mark.parametrize("li,T,nbr,B", RAGGED)
@@ -359,6 +362,7 @@ def test_k_split_cv7_cv8_equal_the_unsplit_kernels(li, T):
     outs = {}
     try:
         for mode in ("0", "2", "4", "8", None):
+            assert L.zns_test_set_tuning(_lib.ZNS_TUNE_ONE_ROW_DIRECT, 1) == 0       # (the default for these layers is the spectral form)
             assert L.zns_test_set_tuning(_lib.ZNS_TUNE_KSPLIT, -1 if mode is None else int(mode)) == 0
             ws = _ops.workspace(_ops.conv_workspace_bytes(nbr, B, T), torch.device(DEV), 0)
             y, _, _ = _ops.conv_fwd(li, nbr, B, T, x, w, b, 0.1, 77, False, ws)
@@ -366,6 +370,7 @@ def test_k_split_cv7_cv8_equal_the_unsplit_kernels(li, T):
             outs[mode] = (y.clone(), dx.clone())
     finally:
         L.zns_test_set_tuning(_lib.ZNS_TUNE_KSPLIT, -1)
+        L.zns_test_set_tuning(_lib.ZNS_TUNE_ONE_ROW_DIRECT, 0)
     y0, d0 = outs["0"]
     assert torch.equal(outs[None][0], outs["8"][0]) and torch.equal(outs[None][1], outs["8"][1])   # T-only rule: all eight
     for mode in ("2", "4", "8"):

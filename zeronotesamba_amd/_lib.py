@@ -76,7 +76,7 @@ ZNS_XQT_SEPARATE, ZNS_XQT_FUSED, ZNS_XQT_EXACT = 4, 8, 16
 ZNS_ERR_MODE = -3
 # include/zns_test.h: keys of zns_test_set_tuning (tests / tools only; the library reads no environment variable)
 (ZNS_TUNE_KSPLIT, ZNS_TUNE_IPW, ZNS_TUNE_XQT_PLAN, ZNS_TUNE_XQT_LDS_PAD, ZNS_TUNE_XQT_TPW, ZNS_TUNE_XQT_CHUNKS,
- ZNS_TUNE_XQT_DBG, ZNS_TUNE_XQT_STAMPS, ZNS_TUNE_WIN128, ZNS_TUNE_XQT_WAVES16, ZNS_TUNE_COUNT) = range(11)
+ ZNS_TUNE_XQT_DBG, ZNS_TUNE_XQT_STAMPS, ZNS_TUNE_WIN128, ZNS_TUNE_XQT_WAVES16, ZNS_TUNE_ONE_ROW_DIRECT, ZNS_TUNE_COUNT) = range(12)
 
 
 def lib() -> C.CDLL:

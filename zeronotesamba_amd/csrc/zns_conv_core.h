@@ -568,11 +568,16 @@ __global__ void __launch_bounds__(C::NT) conv_core(CoreArgs A) {
         return;
     } else if constexpr (C::DILMAX > 0 && C::KH == 1 && C::NCC % 2 == 0 && C::CT > 1) {
         // (TAC carries the live column-tile count here; the barriers inside pair up: same trip counts)
-        if (live_ct >= C::CT) k_stages(std::integral_constant<int, C::CT>{});
-        else if (live_ct == 1) k_stages(std::integral_constant<int, 1>{});
-        else if (C::CT > 2 && live_ct == 2) k_stages(std::integral_constant<int, (C::CT > 2 ? 2 : C::CT)>{});
-        else if (C::CT > 3 && live_ct == 3) k_stages(std::integral_constant<int, (C::CT > 3 ? 3 : C::CT)>{});
-        else k_stages(std::integral_constant<int, (C::CT > 4 ? 4 : C::CT)>{});
+        auto by_live = [&](auto self, auto NC) {
+            constexpr int NL = decltype(NC)::value;
+            if constexpr (NL >= C::CT) {
+                k_stages(std::integral_constant<int, C::CT>{});      // (also the idle waves: they only load and meet the barriers)
+            } else {
+                if (live_ct == NL) k_stages(std::integral_constant<int, NL>{});
+                else self(self, std::integral_constant<int, NL + 1>{});
+            }
+        };
+        by_live(by_live, std::integral_constant<int, 1>{});
     } else if constexpr (C::KH == 1 && C::NCC % 2 == 0) {
         // a K-split workgroup runs through its kp parts like the two-kind layout through its items: the next part's first slab
         // and patch are requested during the current part's last stage (NST is even: buffers 0 are free again)

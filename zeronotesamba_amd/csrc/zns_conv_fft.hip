@@ -65,7 +65,7 @@ __device__ __forceinline__ void spec_store(__amdgpu_buffer_rsrc_t rs, unsigned v
 template <int FN>
 __global__ void __launch_bounds__(256) spec_fwd_kernel(const float* __restrict__ x, float* __restrict__ S, int C,
                                                        int H, int T, int V, int NB, int off, int valid, int chunks,
-                                                       float third_sign, int NS, int NBT, float* __restrict__ S2) {
+                                                       float third_sign, int NS, int NBT, float* __restrict__ S2, int remap) {
     constexpr int FF = FN / 2, FS = 3 * FF, WINB = win_per_block<FN>(), K64 = FN / 64, WPW = WINB / 4;   // WPW: windows a wave fetches
     // Windows are staged through LDS so that global reads are coalesced: one wave-instruction fetches ONE window
     // (64 consecutive samples); all 64 fetches of a wave are issued before the first LDS write.  Each lane then
@@ -90,7 +90,9 @@ __global__ void __launch_bounds__(256) spec_fwd_kernel(const float* __restrict__
             for (int h = 0; h < K64; ++h) {           // a 128-sample window is two wave-instructions
                 const int smp = lane + 64 * h;
                 const int col = (bseg + bb) * V - off + smp;
-                xw[i * K64 + h] = (i < left && bseg + bb < NBT && smp < valid && col >= 0 && col < T) ? xn[(size_t)R * T + col] : 0.f;
+                // remap (the one-row layers, see geom()): the H "rows" of a channel are the samples of the batch, x is [H][C][T]
+                const size_t ro = remap ? ((size_t)(R % H) * C + R / H) * T : (size_t)R * T;
+                xw[i * K64 + h] = (i < left && bseg + bb < NBT && smp < valid && col >= 0 && col < T) ? xn[ro + col] : 0.f;
             }
             if (++bb == NB) { bb = 0; ++R; }
         }
@@ -189,6 +191,7 @@ struct InvEpi {
     int prev_pool;
     uint32_t mV, mNB, mHq;     // ceil(2^32 / d) for the epilogue's index divisions (exact for x * d < 2^32)
     uint32_t mT, mPP;          // FLAT epilogue: divisions by T and by prev_pool
+    int remap;                 // the one-row layers (geom()): rows are the samples of the batch, tensors are [H][C][T] (scalar epilogue only)
 };
 
 template <int FN> constexpr int iv_max() { return FN - 12; }     // V <= FN - 12 (kw >= 13)
@@ -482,7 +485,7 @@ __global__ void __launch_bounds__(inv_threads<FN>()) spec_inv_kernel(const float
     for (int e0 = threadIdx.x; e0 < nout; e0 += NTHR * EU) {
         float r[EU], mk[EU];
         size_t o[EU];
-        int am[EU], Rq[EU], col[EU];
+        int am[EU], Rq[EU], col[EU], orow[EU];
         bool ok[EU];
 #pragma unroll
         for (int u = 0; u < EU; ++u) {
@@ -492,7 +495,13 @@ __global__ void __launch_bounds__(inv_threads<FN>()) spec_inv_kernel(const float
             col[u] = (bseg + b) * V + v;
             ok[u] = e < nout && col[u] < T;
             Rq[u] = Rq0 + lg;                                          // = c * Hq + hq
-            o[u] = ((size_t)n * C * Hq + Rq[u]) * T + col[u];
+            if (E.remap) {                                             // tensor row of (c, hq): hq * C + c
+                const int c = fastdiv(Rq[u], Hq, E.mHq);
+                orow[u] = (Rq[u] - c * Hq) * C + c;
+            } else {
+                orow[u] = Rq[u];
+            }
+            o[u] = ((size_t)n * C * Hq + orow[u]) * T + col[u];
             r[u] = 0.f;
             am[u] = 0;
             mk[u] = 1.f;
@@ -520,7 +529,7 @@ __global__ void __launch_bounds__(inv_threads<FN>()) spec_inv_kernel(const float
                 rr += mk[u];
                 rr = relu_nan(rr);
                 if (E.thresh) {
-                    const uint64_t idx = ((uint64_t)bb * C * Hq + Rq[u]) * T + col[u];
+                    const uint64_t idx = ((uint64_t)bb * C * Hq + orow[u]) * T + col[u];
                     rr = drop_apply(drop_keep(lseed, idx, E.thresh), rr, E.inv_keep);
                 }
                 out[o[u]] = rr;
@@ -529,7 +538,7 @@ __global__ void __launch_bounds__(inv_threads<FN>()) spec_inv_kernel(const float
                 if (E.xmask) rr = (mk[u] != 0.f) ? rr * E.inv_keep : 0.f;
                 const int pp = E.prev_pool;
                 if (pp > 1) {
-                    float* d = out + (((size_t)n * C * Hq + Rq[u]) * pp) * T + col[u];
+                    float* d = out + (((size_t)n * C * Hq + orow[u]) * pp) * T + col[u];
                     for (int q = 0; q < pp; ++q) d[(size_t)q * T] = (q == am[u]) ? rr : 0.f;
                 } else {
                     out[o[u]] = rr;
@@ -758,6 +767,13 @@ using FF3w = ConvCfg<64, 128, 1, 5, 1, 1, 1, 5, 4, 1, 1, 8, 1, 1, FDIL128>;
 using FF3wa = ConvCfg<64, 128, 1, 5, 1, 1, 1, 3, 4, 1, 1, 8, 1, 1, FDIL128>;
 using FF4w = ConvCfg<128, 128, 1, 9, 1, 1, 1, 5, 4, 1, 1, 4, 1, 1, FDIL128>;
 using FF4wa = ConvCfg<128, 128, 1, 9, 1, 1, 1, 3, 4, 1, 1, 4, 1, 1, FDIL128>;
+// cv7 / cv8 (see geom(): remap): one GEMM per (branch, slot), 32-channel stages, a wave = one channel tile x up to seven column
+// tiles (224 columns per block: T = 512 has P = 208; the dead tiles of shorter axes are skipped: live-tile K loops)
+//                  CIN COUT KH KW(taps) H  MT RT CT WM WR WC CK POOL EPI DILMAX
+using FF7 = ConvCfg<256, 128, 1, 1, 1, 1, 1, 7, 4, 1, 1, 32, 1, 1, FDIL>;
+using FD7 = ConvCfg<128, 256, 1, 1, 1, 1, 1, 7, 8, 1, 1, 32, 1, 1, FDIL>;
+using FF8 = ConvCfg<128, 128, 1, 1, 1, 1, 1, 7, 4, 1, 1, 32, 1, 1, FDIL>;
+using FD8 = FF8;
 using FD4w = FF4w;
 using FD4wa = FF4wa;
 // cv3 backward-data (two channel tiles x five column tiles): four waves of (1 x 3) over 192 columns, the sixth column tile
@@ -787,6 +803,10 @@ using FW3 = WgCfg<64, 128, 1, 5, 1, 1, 5, 4, 1, 1, FDILW, 2, 32>;
 using FW4 = WgCfg<128, 128, 1, 9, 1, 2, 3, 2, 3, 1, FDILW, 2, 32>;
 using FW5 = WgCfg<128, 256, 1, 3, 1, 2, 3, 2, 1, 1, FDILW, 2, 32>;
 using FW6 = WgCfg<256, 256, 1, 5, 1, 2, 5, 4, 1, 1, FDILW, 2, 32>;
+// cv7 / cv8 as one GEMM per (branch, slot) (see geom(): remap): a single "tap"; 8 waves = 2 output-channel groups of 2 tiles x 4
+// input-channel tiles, 128 x 128 of dW per workgroup
+using FW7 = WgCfg<256, 128, 1, 1, 1, 2, 1, 2, 1, 1, FDILW, 4, 32>;
+using FW8 = WgCfg<128, 128, 1, 1, 1, 2, 1, 2, 1, 1, FDILW, 4, 32>;
 
 struct FftGeom {
     int FN;     // window length: 64 or 128 samples
@@ -798,13 +818,15 @@ struct FftGeom {
     int P;      // flattened (row, window) positions per channel of one spectral sample
     int nb;     // spectral samples = nbr * B * NS
     int Bs;     // spectral samples per branch = B * NS
+    int remap;  // cv7 / cv8 (one image row, kh = 1): see geom()
+    int H;      // rows of a spectral sample (remap: the samples of a branch)
 };
 
 static int fft_layer_of(const ConvArgs& a) {
     struct L { int cin, cout, kh, kw, H; };
     static const L tab[] = {{64, 64, 7, 13, 96}, {64, 128, 5, 15, 32}, {128, 128, 9, 17, 32}, {128, 256, 3, 19, 8},
-                            {256, 256, 5, 21, 8}};
-    for (int i = 0; i < 5; ++i)
+                            {256, 256, 5, 21, 8}, {256, 128, 1, 23, 1}, {128, 128, 1, 25, 1}};
+    for (int i = 0; i < 7; ++i)
         if (tab[i].cin == a.cin && tab[i].cout == a.cout && tab[i].kh == a.kh && tab[i].kw == a.kw && tab[i].H == a.H)
             return i + 2;
     return -1;
@@ -825,8 +847,31 @@ static bool use_win128(const ConvArgs& a) {
     return 2 * n128 < ceil_div(a.T, 65 - a.kw);
 }
 
+// cv7 / cv8 have ONE image row and kh = 1: per sample the flattened (row, window) axis would be 8 .. 13 positions, a sliver of
+// a 32-column tile.  Without row taps nothing couples the positions of a launch, so the samples of a branch become the ROWS of
+// one spectral sample per branch -- "H" = B, P = B * NBT (T = 512: 208, the reference's T = 313: 128) -- and every (branch,
+// slot) is one plain GEMM  [cout x cin] x [cin x P]  on the matrix cores: 96 real MACs per 42- / 40-sample window instead of
+// 23 / 25 per sample, 10x fewer than the direct form these layers ran in until round 5.  The transforms address the
+// [B][C][T] tensors through a row remap (spec_fwd_kernel / spec_inv_kernel: remap); rows are never cut (no taps: any NB).
+constexpr int ONE_ROW_MAX_NB = 256;     // the inverse transform's block holds a whole row of windows
+
 static FftGeom geom(const ConvArgs& a) {
     FftGeom g;
+    g.remap = fft_layer_of(a) >= 7 ? 1 : 0;
+    if (g.remap) {
+        g.FN = 64;
+        g.FS = 96;
+        g.V = g.FN - a.kw + 1;
+        g.NBT = ceil_div(a.T, g.V);
+        g.NS = 1;
+        g.NB = g.NBT;
+        g.H = a.B;
+        g.P = a.B * g.NB;
+        g.Bs = 1;
+        g.nb = a.nbr;
+        return g;
+    }
+    g.H = a.H;
     g.FN = use_win128(a) ? 128 : 64;
     g.FS = 3 * (g.FN / 2);
     g.V = g.FN - a.kw + 1;
@@ -840,7 +885,9 @@ static FftGeom geom(const ConvArgs& a) {
 }
 
 bool fft_supported(const ConvArgs& a) {
-    if (fft_layer_of(a) < 0 || a.nbr < 1 || a.nbr > 2) return false;
+    const int l = fft_layer_of(a);
+    if (l < 0 || a.nbr < 1 || a.nbr > 2) return false;
+    if (l >= 7 && (tuning(ZNS_TUNE_ONE_ROW_DIRECT) > 0 || ceil_div(a.T, 65 - a.kw) > ONE_ROW_MAX_NB)) return false;
     return a.T >= 32 && a.B >= 1;
 }
 
@@ -884,6 +931,8 @@ static FftWs fft_ws(const ConvArgs& a) {
         case 4: slab = fwg_slab_floats<FW4>(a, g); break;
         case 5: slab = fwg_slab_floats<FW5>(a, g); break;
         case 6: slab = fwg_slab_floats<FW6>(a, g); break;
+        case 7: slab = fwg_slab_floats<FW7>(a, g); break;
+        case 8: slab = fwg_slab_floats<FW8>(a, g); break;
     }
     slab *= sizeof(float);
     w.slab = w.wf;   // backward-weights does not need the packed frequency weights: same region
@@ -903,14 +952,15 @@ size_t fft_dz_spectrum_bytes(const ConvArgs& a) {
 
 static int run_spec_fwd(const float* x, float* S, int nb, int C, int H, int T, const FftGeom& g, int off, int valid,
                         float third_sign, hipStream_t st, float* S2 = nullptr) {
+    const int remap = g.remap;
     if (g.FN == 128) {
         const int chunks = ceil_div(C * g.P, win_per_block<128>());
         hipLaunchKernelGGL(spec_fwd_kernel<128>, dim3((unsigned)((size_t)nb * chunks)), dim3(256), 0, st, x, S,
-                           C, H, T, g.V, g.NB, off, valid, chunks, third_sign, g.NS, g.NBT, S2);
+                           C, H, T, g.V, g.NB, off, valid, chunks, third_sign, g.NS, g.NBT, S2, remap);
     } else {
         const int chunks = ceil_div(C * g.P, 256);
         hipLaunchKernelGGL(spec_fwd_kernel<64>, dim3((unsigned)((size_t)nb * chunks)), dim3(256), 0, st, x, S, C, H, T, g.V,
-                           g.NB, off, valid, chunks, third_sign, g.NS, g.NBT, S2);
+                           g.NB, off, valid, chunks, third_sign, g.NS, g.NBT, S2, remap);
     }
     ZNS_LAUNCH_CHECK();
     return ZNS_OK;
@@ -925,9 +975,10 @@ static int run_spec_inv_n(const float* S, float* out, int nb, int C, int H, int 
     const int WPB = (WINB / group) * group;
     const int chunks = ceil_div(C * g.P, WPB);
     auto al = [](const void* p, int a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; };
+    E.remap = g.remap;
     int vw = 1;   // samples per thread in the epilogue: the widest vector V, T and every pointer allow
     for (int cand : {4, 2})
-        if (vw == 1 && g.V % cand == 0 && T % cand == 0 && al(out, 4 * cand) && al(E.xmask, 4 * cand) && al(E.argmax, cand) &&
+        if (!g.remap && vw == 1 && g.V % cand == 0 && T % cand == 0 && al(out, 4 * cand) && al(E.xmask, 4 * cand) && al(E.argmax, cand) &&
             al(E.prev_argmax, cand))
             vw = cand;
     // V % 4 == 2 on a one-segment row: 16-byte chunks along the row instead of 8-byte chunks along the windows
@@ -939,7 +990,7 @@ static int run_spec_inv_n(const float* S, float* out, int nb, int C, int H, int 
     const size_t lds = (size_t)WINB * (vw > 1 ? g.V : (g.V | 1)) * sizeof(float);
     const dim3 grid((unsigned)((size_t)nb * chunks));
     // everything else on a one-segment row (odd T, e.g. the reference's 313 frames): 16-byte chunks of the block's flat output
-    const bool flat = !row && vw < 4 && g.NS == 1 && al(out, 16) && al(E.argmax, 4) && al(E.xmask, 16);
+    const bool flat = !g.remap && !row && vw < 4 && g.NS == 1 && al(out, 16) && al(E.argmax, 4) && al(E.xmask, 16);
     E.mT = div_magic(T);
     E.mPP = div_magic(MODE == 2 ? E.prev_pool : 1);
     if (flat) {
@@ -1026,7 +1077,7 @@ static int run_fconv(const ConvArgs& a, const FftGeom& g, Ptr2 w, int transposed
     A.F = g.FS;
     A.dil = g.NB;
     A.ncb = ceil_div(g.P, C::WB);
-    if ((C::DILMAX == FDIL128) != (g.FN == 128) || g.NB > C::DILMAX) {
+    if ((C::DILMAX == FDIL128) != (g.FN == 128) || (C::KW > 1 && g.NB > C::DILMAX)) {
         set_error("conv (fft): tile configuration and window length disagree (FN %d, NB %d)", g.FN, g.NB);
         return ZNS_ERR_ARG;
     }
@@ -1066,7 +1117,7 @@ static int fft_fwd_t(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float
     float* s_in = xspec ? xspec : (float*)(base + L.s_in);   // kept by the caller for backward-weights when given
     float* s_out = (float*)(base + L.s_out);
     float* wf = (float*)(base + L.wf);
-    int rc = run_spec_fwd(x, s_in, g.nb, a.cin, a.H, a.T, g, a.kw / 2, g.FN, 1.f, st);
+    int rc = run_spec_fwd(x, s_in, g.nb, a.cin, g.H, a.T, g, a.kw / 2, g.FN, 1.f, st);
     if (rc) return rc;
     rc = run_fconv<C>(a, g, w, 0, s_in, s_out, wf, wpk, 0, st);
     if (rc) return rc;
@@ -1074,12 +1125,12 @@ static int fft_fwd_t(const ConvArgs& a, const float* x, Ptr2 w, Ptr2 bias, float
     E.bias = bias;
     E.argmax = argmax;
     E.pool = a.pool;
-    E.B = a.B;
+    E.B = g.remap ? 1 : a.B;          // samples of a branch per spectral-sample index
     E.thresh = drop_p > 0.f ? drop_threshold(drop_p) : 0u;
     E.inv_keep = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.f;
     E.seed = seed;
     E.layer = layer;
-    return run_spec_inv<1>(s_out, y, g.nb, a.cout, a.H, a.T, g, E, st);
+    return run_spec_inv<1>(s_out, y, g.nb, a.cout, g.H, a.T, g, E, st);
 }
 
 template <class C>
@@ -1095,7 +1146,7 @@ static int fft_dgrad_t(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, co
     float* wf = (float*)(base + L.wf);
     int rc = ZNS_OK;
     if (dzspec) s_in = const_cast<float*>(dzspec);           // written by the preceding backward-weights call
-    else rc = run_spec_fwd(dz, s_in, g.nb, a.cout, a.H, a.T, g, a.kw / 2, g.FN, 1.f, st);
+    else rc = run_spec_fwd(dz, s_in, g.nb, a.cout, g.H, a.T, g, a.kw / 2, g.FN, 1.f, st);
     if (rc) return rc;
     rc = run_fconv<C>(a, g, w, 1, s_in, s_out, wf, wpk, 1, st);
     if (rc) return rc;
@@ -1104,7 +1155,7 @@ static int fft_dgrad_t(const ConvArgs& a, const float* dz, Ptr2 w, float* dx, co
     E.inv_keep = inv_keep;
     E.prev_argmax = prev_argmax;
     E.prev_pool = prev_pool;
-    return run_spec_inv<2>(s_out, dx, g.nb, a.cin, a.H, a.T, g, E, st);
+    return run_spec_inv<2>(s_out, dx, g.nb, a.cin, g.H, a.T, g, E, st);
 }
 
 template <class W>
@@ -1119,12 +1170,12 @@ static int fft_wgrad_t(const ConvArgs& a, const float* dz, const float* x, MPtr2
     float* slab = (float*)(base + L.slab);
     int rc = ZNS_OK;
     if (xspec) sx = const_cast<float*>(xspec);                                         // saved by the forward call
-    else rc = run_spec_fwd(x, sx, g.nb, a.cin, a.H, a.T, g, a.kw / 2, g.FN, 1.f, st);   // windows of the input: (xr, xi, xr+xi)
+    else rc = run_spec_fwd(x, sx, g.nb, a.cin, g.H, a.T, g, a.kw / 2, g.FN, 1.f, st);   // windows of the input: (xr, xi, xr+xi)
     if (rc) return rc;
     if (dzspec_out)   // one pass over dZ: overlapped windows for the backward-data call + the zero-padded V-blocks
-        rc = run_spec_fwd(dz, dzspec_out, g.nb, a.cout, a.H, a.T, g, a.kw / 2, g.FN, 1.f, st, sz);
+        rc = run_spec_fwd(dz, dzspec_out, g.nb, a.cout, g.H, a.T, g, a.kw / 2, g.FN, 1.f, st, sz);
     else
-        rc = run_spec_fwd(dz, sz, g.nb, a.cout, a.H, a.T, g, 0, g.V, -1.f, st);  // zero-padded V-blocks of dZ: (r, i, r-i)
+        rc = run_spec_fwd(dz, sz, g.nb, a.cout, g.H, a.T, g, 0, g.V, -1.f, st);  // zero-padded V-blocks of dZ: (r, i, r-i)
     if (rc) return rc;
     rc = set_lds_fw<W>(wgrad_core<W>);
     if (rc) return rc;
@@ -1200,6 +1251,8 @@ static int with_cfg(const ConvArgs& a, int transposed, Fn&& f) {
         case 6:
             if (transposed) return use_narrow<FD6, FD6a>(a) ? f(cfg_tag<FD6a>{}) : f(cfg_tag<FD6>{});
             return use_narrow<FF6, FF6a>(a) ? f(cfg_tag<FF6a>{}) : f(cfg_tag<FF6>{});
+        case 7: return transposed ? f(cfg_tag<FD7>{}) : f(cfg_tag<FF7>{});
+        case 8: return transposed ? f(cfg_tag<FD8>{}) : f(cfg_tag<FF8>{});
     }
     return ZNS_ERR_ARG;
 }
@@ -1248,6 +1301,8 @@ int fft_wgrad(const ConvArgs& a, const float* dz, const float* x, MPtr2 dw, MPtr
         case 4: return fft_wgrad_t<FW4>(a, dz, x, dw, db, accumulate, xspec, dzspec_out, ws, ws_bytes, st);
         case 5: return fft_wgrad_t<FW5>(a, dz, x, dw, db, accumulate, xspec, dzspec_out, ws, ws_bytes, st);
         case 6: return fft_wgrad_t<FW6>(a, dz, x, dw, db, accumulate, xspec, dzspec_out, ws, ws_bytes, st);
+        case 7: return fft_wgrad_t<FW7>(a, dz, x, dw, db, accumulate, xspec, dzspec_out, ws, ws_bytes, st);
+        case 8: return fft_wgrad_t<FW8>(a, dz, x, dw, db, accumulate, xspec, dzspec_out, ws, ws_bytes, st);
     }
     return ZNS_ERR_ARG;
 }
