@@ -474,3 +474,59 @@ def test_nothing_reads_the_unused_third_plane_of_frequency_slot_0(li, T, nbr, B,
     assert torch.isfinite(c[0]).all() and torch.isfinite(c[1]).all()
     assert torch.equal(a[0], c[0]) and torch.equal(a[1], c[1]), name
     assert all(torch.equal(u, v) for u, v in zip(a[2], c[2])) and all(torch.equal(u, v) for u, v in zip(a[3], c[3])), name
+
+
+@pytest.mark.parametrize("li", [6, 7])
+@pytest.mark.parametrize("T,nbr,B", [(512, 2, 16), (313, 2, 16), (626, 1, 3), (1876, 1, 1), (33, 2, 1), (45, 1, 5), (3751, 1, 1)])
+def test_one_row_layers_in_the_frequency_domain_equal_the_direct_kernels(li, T, nbr, B):
+    """cv7 / cv8 (one image row, kh = 1) run as ONE GEMM per (branch, frequency slot) with the samples of a branch as the rows
+    of a single spectral sample (zns_conv_fft.hip: geom(), remap) against the direct MFMA kernels they ran on until round 5
+    (ZNS_TUNE_ONE_ROW_DIRECT = 1): forward with dropout, backward-data with the mask and cv6's 8-row unpool (cv7), backward-
+    weights and bias gradient, spectra handed from call to call -- 2e-5 of each result's scale (the same fp32 products in
+    another order); the dropout / mask / arg-max decisions are index hashes and inputs, identical on both sides."""
+    _lib, _ops = _mods()
+    L = _lib.lib()
+    name, cin, cout, kh, kw, pool = _ops.LAYERS[li]
+    H = _ops.H_IN[li]
+    assert H == 1 and kh == 1
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(900 * li + T + B)
+    x = torch.randn((nbr * B, cin, H, T), generator=g).clamp_(min=0).to(dev)
+    w = [(torch.randn((cout, cin, kh, kw), generator=g) / (cin * kh * kw) ** 0.5).to(dev) for _ in range(nbr)]
+    b = [(torch.randn((cout,), generator=g) * 0.1).to(dev) for _ in range(nbr)]
+    dz = torch.randn((nbr * B, cout, H, T), generator=g).to(dev)
+    pp = _ops.LAYERS[li - 1][5]
+    am_prev = torch.randint(0, pp, (nbr * B, cin, H, T), generator=g, dtype=torch.uint8).to(dev) if pp > 1 else None
+    outs = {}
+    try:
+        for direct in (1, 0):
+            assert L.zns_test_set_tuning(_lib.ZNS_TUNE_ONE_ROW_DIRECT, direct) == 0
+            ws = _ops.workspace(_ops.conv_workspace_bytes(nbr, B, T), dev, 0)
+            y, am, spec = _ops.conv_fwd(li, nbr, B, T, x, w, b, 0.1, 77, True, ws)
+            assert (spec is None) == bool(direct)            # the spectral form keeps the input spectrum for backward-weights
+            dw = [torch.zeros_like(t) for t in w]
+            db = [torch.zeros_like(t) for t in b]
+            dzs = _ops.dz_spectrum(li, nbr, B, T, dev)
+            _ops.conv_wgrad(li, nbr, B, T, dz, x, dw, db, False, ws, xspec=spec, dzspec_out=dzs)
+            dx = _ops.conv_dgrad(li, nbr, B, T, dz, w, x, 1.0 / 0.9, am_prev, pp, ws, dzspec=dzs)
+            dx2 = _ops.conv_dgrad(li, nbr, B, T, dz, w, x, 1.0 / 0.9, am_prev, pp, ws)
+            torch.cuda.synchronize()
+            assert torch.equal(dx, dx2)
+            outs[direct] = (y.clone(), dx.clone(), [t.clone() for t in dw], [t.clone() for t in db])
+    finally:
+        L.zns_test_set_tuning(_lib.ZNS_TUNE_ONE_ROW_DIRECT, 0)
+    a, c = outs[1], outs[0]
+
+    def near(u, v, what, tol=2e-5):
+        s = v.abs().max().item()
+        e = (u - v).abs().max().item()
+        assert e <= tol * max(s, 1e-30), f"{name} T={T} B={B} {what}: {e:.3e} of {s:.3e}"
+    near(c[0], a[0], "forward")
+    # (a pre-activation within rounding of 0 may land on the other side of the ReLU: both values are then ~0)
+    assert ((c[0] == 0) != (a[0] == 0)).sum().item() <= 1e-4 * a[0].numel()
+    near(c[1], a[1], "backward-data")
+    assert torch.equal(c[1] == 0, a[1] == 0) or ((c[1] == 0) != (a[1] == 0)).sum().item() < 1e-5 * a[1].numel()
+    for u, v in zip(c[2], a[2]):
+        near(u, v, "backward-weights")
+    for u, v in zip(c[3], a[3]):
+        near(u, v, "bias gradient")

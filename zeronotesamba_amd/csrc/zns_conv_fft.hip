@@ -191,7 +191,7 @@ struct InvEpi {
     int prev_pool;
     uint32_t mV, mNB, mHq;     // ceil(2^32 / d) for the epilogue's index divisions (exact for x * d < 2^32)
     uint32_t mT, mPP;          // FLAT epilogue: divisions by T and by prev_pool
-    int remap;                 // the one-row layers (geom()): rows are the samples of the batch, tensors are [H][C][T] (scalar epilogue only)
+    int remap;                 // the one-row layers (geom()): rows are the samples of the batch, tensors are [H][C][T] (not ROW / FLAT)
 };
 
 template <int FN> constexpr int iv_max() { return FN - 12; }     // V <= FN - 12 (kw >= 13)
@@ -404,7 +404,7 @@ __global__ void __launch_bounds__(inv_threads<FN>()) spec_inv_kernel(const float
             vec_t r[EV], mk[EV];
             uint32_t amw[EV];
             size_t o[EV];
-            int Rq[EV], col[EV];
+            int Rq[EV], col[EV], orow[EV];
             bool ok[EV];
 #pragma unroll
             for (int u = 0; u < EV; ++u) {
@@ -414,7 +414,13 @@ __global__ void __launch_bounds__(inv_threads<FN>()) spec_inv_kernel(const float
                 col[u] = ROW ? v : (bseg + b) * V + v;
                 ok[u] = e < nout4 && col[u] < T;
                 Rq[u] = Rq0 + lg;
-                o[u] = ((size_t)n * C * Hq + Rq[u]) * T + col[u];
+                if (E.remap) {                                         // tensor row of (c, hq): hq * C + c
+                    const int c = fastdiv(Rq[u], Hq, E.mHq);
+                    orow[u] = (Rq[u] - c * Hq) * C + c;
+                } else {
+                    orow[u] = Rq[u];
+                }
+                o[u] = ((size_t)n * C * Hq + orow[u]) * T + col[u];
 #pragma unroll
                 for (int k = 0; k < VW; ++k) { r[u][k] = 0.f; mk[u][k] = 1.f; }
                 amw[u] = 0u;
@@ -450,7 +456,7 @@ __global__ void __launch_bounds__(inv_threads<FN>()) spec_inv_kernel(const float
                         float t = rr[k] + mk[u][k];
                         t = relu_nan(t);
                         if (E.thresh) {
-                            const uint64_t idx = ((uint64_t)bb * C * Hq + Rq[u]) * T + col[u] + k;
+                            const uint64_t idx = ((uint64_t)bb * C * Hq + orow[u]) * T + col[u] + k;
                             t = drop_apply(drop_keep(lseed, idx, E.thresh), t, E.inv_keep);
                         }
                         rr[k] = t;
@@ -464,7 +470,7 @@ __global__ void __launch_bounds__(inv_threads<FN>()) spec_inv_kernel(const float
                     }
                     const int pp = E.prev_pool;
                     if (pp > 1) {
-                        float* d = out + (((size_t)n * C * Hq + Rq[u]) * pp) * T + col[u];
+                        float* d = out + (((size_t)n * C * Hq + orow[u]) * pp) * T + col[u];
                         for (int q = 0; q < pp; ++q) {
                             vec_t t;
 #pragma unroll
@@ -768,11 +774,12 @@ using FF3wa = ConvCfg<64, 128, 1, 5, 1, 1, 1, 3, 4, 1, 1, 8, 1, 1, FDIL128>;
 using FF4w = ConvCfg<128, 128, 1, 9, 1, 1, 1, 5, 4, 1, 1, 4, 1, 1, FDIL128>;
 using FF4wa = ConvCfg<128, 128, 1, 9, 1, 1, 1, 3, 4, 1, 1, 4, 1, 1, FDIL128>;
 // cv7 / cv8 (see geom(): remap): one GEMM per (branch, slot), 32-channel stages, a wave = one channel tile x up to seven column
-// tiles (224 columns per block: T = 512 has P = 208; the dead tiles of shorter axes are skipped: live-tile K loops)
+// tiles (128 columns per block: T = 313 has P = 128, T = 512 P = 208 = 4 + 3 live tiles; two workgroups per CU; seven tiles per
+// wave in one block: 190 workgroups of one wave per SIMD, 45 us against 30)
 //                  CIN COUT KH KW(taps) H  MT RT CT WM WR WC CK POOL EPI DILMAX
-using FF7 = ConvCfg<256, 128, 1, 1, 1, 1, 1, 7, 4, 1, 1, 32, 1, 1, FDIL>;
-using FD7 = ConvCfg<128, 256, 1, 1, 1, 1, 1, 7, 8, 1, 1, 32, 1, 1, FDIL>;
-using FF8 = ConvCfg<128, 128, 1, 1, 1, 1, 1, 7, 4, 1, 1, 32, 1, 1, FDIL>;
+using FF7 = ConvCfg<256, 128, 1, 1, 1, 1, 1, 4, 4, 1, 1, 32, 1, 1, FDIL>;
+using FD7 = ConvCfg<128, 256, 1, 1, 1, 1, 1, 4, 8, 1, 1, 32, 1, 1, FDIL>;
+using FF8 = ConvCfg<128, 128, 1, 1, 1, 1, 1, 4, 4, 1, 1, 32, 1, 1, FDIL>;
 using FD8 = FF8;
 using FD4w = FF4w;
 using FD4wa = FF4wa;
@@ -978,11 +985,11 @@ static int run_spec_inv_n(const float* S, float* out, int nb, int C, int H, int 
     E.remap = g.remap;
     int vw = 1;   // samples per thread in the epilogue: the widest vector V, T and every pointer allow
     for (int cand : {4, 2})
-        if (!g.remap && vw == 1 && g.V % cand == 0 && T % cand == 0 && al(out, 4 * cand) && al(E.xmask, 4 * cand) && al(E.argmax, cand) &&
+        if (vw == 1 && g.V % cand == 0 && T % cand == 0 && al(out, 4 * cand) && al(E.xmask, 4 * cand) && al(E.argmax, cand) &&
             al(E.prev_argmax, cand))
             vw = cand;
     // V % 4 == 2 on a one-segment row: 16-byte chunks along the row instead of 8-byte chunks along the windows
-    const bool row = vw == 2 && g.NS == 1 && T % 4 == 0 && al(out, 16) && al(E.xmask, 16) && al(E.argmax, 4) &&
+    const bool row = !g.remap && vw == 2 && g.NS == 1 && T % 4 == 0 && al(out, 16) && al(E.xmask, 16) && al(E.argmax, 4) &&
                      al(E.prev_argmax, 4);
     E.mV = div_magic(row ? T / 4 : g.V / vw);
     E.mNB = div_magic(g.NB);
