@@ -39,7 +39,8 @@ MACS = {"cv1": 1.038e8, "cv2": 1.832e10, "cv3": 1.007e10, "cv4": 4.107e10, "cv5"
 STEP_FLOP = B * 2 * 2 * (3 * sum(MACS.values()) - MACS["cv1"])   # fwd + dgrad + wgrad, no cv1 dgrad
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 LAYER_GEOM = {"cv2": (64, 64, 7, 13, 96), "cv3": (64, 128, 5, 15, 32), "cv4": (128, 128, 9, 17, 32),
-              "cv5": (128, 256, 3, 19, 8), "cv6": (256, 256, 5, 21, 8)}   # cin, cout, kh, kw, H
+              "cv5": (128, 256, 3, 19, 8), "cv6": (256, 256, 5, 21, 8),
+              "cv7": (256, 128, 1, 23, 1), "cv8": (128, 128, 1, 25, 1)}   # cin, cout, kh, kw, H
 
 
 def window_length(layer: str, frames: int) -> int:
@@ -56,28 +57,32 @@ def window_length(layer: str, frames: int) -> int:
 def spectral_flop(layer: str, useful: bool, frames: int = T, samples: int = 2 * B) -> float:
     """FLOP of ONE pass (fwd, dgrad or wgrad) of `layer` in the frequency-domain form over `samples` spectrograms of
     `frames` columns (default: both branches, B=16, T=512): FN/2 frequencies x 3 real GEMMs (Karatsuba) of
-    cout x (cin*kh) per window position (executed); frequency slot 0 (DC + Nyquist, both real) needs only two of its
-    three (useful).  Rows longer than 12 (64-point) / 6 (128-point) windows run as NS segments of NB windows.  Tile
-    padding is not counted."""
+    cout x (cin*kh) per window position; frequency slot 0 (DC + Nyquist, both real) has only two of the three, and since
+    round 5 the launches skip its third item: executed == useful (`useful` is kept for callers; both give the same count).
+    Rows longer than 12 (64-point) / 6 (128-point) windows run as NS segments of NB windows; cv7 / cv8 (one image row, kh = 1)
+    are one GEMM per (branch, slot) over all samples' windows, never cut.  Tile padding is not counted."""
     cin, cout, kh, kw, H = LAYER_GEOM[layer]
     fn = window_length(layer, frames)
     V = fn - kw + 1
     nbt = -(-frames // V)
-    ns = -(-nbt // (12 if fn == 64 else 6))
-    nb = -(-nbt // ns)
-    P = H * nb * ns
+    if H == 1 and kh == 1:
+        P = nbt
+    else:
+        ns = -(-nbt // (12 if fn == 64 else 6))
+        nb = -(-nbt // ns)
+        P = H * nb * ns
     ff = fn // 2
-    slots = ((ff - 1) * 3 + 2) if useful else ff * 3
+    slots = (ff - 1) * 3 + 2
     return 2.0 * slots * cout * cin * kh * P * samples
 
 
 def exec_flop(frames: int, samples: int) -> float:
-    """MFMA FLOP executed by one training step: cv2..cv6 in the frequency domain (3 passes), cv7/cv8 direct (3 passes)."""
-    return (3 * sum(spectral_flop(l, False, frames, samples) for l in LAYER_GEOM)
-            + 3 * 2 * samples * (MACS["cv7"] + MACS["cv8"]) * frames / 512.0)
+    """MFMA FLOP executed by one training step: cv2..cv8 in the frequency domain (3 passes each; cv1 runs K = 34 GEMMs that
+    are bound by its 2 x 201 MB of activations, not counted)."""
+    return 3 * sum(spectral_flop(l, False, frames, samples) for l in LAYER_GEOM)
 
 
-# MFMA FLOP actually executed per step: cv2..cv6 in the frequency domain (3 passes), cv7/cv8 direct (3 passes)
+# MFMA FLOP actually executed per step: cv2..cv8 in the frequency domain (3 passes)
 EXEC_FLOP = exec_flop(T, 2 * B)
 # dominant kernel (profiles/): the frequency-domain forward GEMM-conv of cv4 (conv_core<128,128,1x9 taps>: 128-point windows,
 # 192 slots per sample, four waves of (1 channel tile x 5 column tiles))
@@ -86,8 +91,9 @@ PROBE = dict(kind=0, cin=128, cout=128, kh=9, name="conv_core<spectral cv4 forwa
              # HBM bytes per launch from separate rocprofv3 --pmc passes, NOT measured by this run: 2 x FETCH_SIZE (gfx950
              # counts the 128-B requests of 16-byte loads as 64 B) + WRITE_SIZE of this kernel's row in PROBE_PMC_FILE.
              # tests/test_bench_contract.py fails when the two drift apart (a new profile set must update both).
-             # (1.233 GB against 1.232 GB algorithmic: 503 MB of input spectrum + 503 MB of output + 226 MB of operators)
-             traffic=(2 * 356483 + 491520) * 1024.0,
+             # (1.227 GB against 1.226 GB algorithmic: 501 MB of input spectrum + 501 MB of output + 225 MB of operators -- 191 of
+             # the 192 slots: frequency slot 0 has no third Karatsuba item)
+             traffic=(2 * 354613 + 488960) * 1024.0,
              traffic_source="constant from separate rocprofv3 --pmc passes (profiles/r05_pmc_summary.csv), 2 x FETCH_SIZE + WRITE_SIZE; not measured by this run")
 PROBE_PMC_FILE = "profiles/r05_pmc_summary.csv"
 PROBE_PMC_KERNEL = "conv_core<ConvCfg<128, 128, 1, 9, 1, 1, 1, 5, 4, 1, 1, 4,"      # cv4 forward / backward-data on 128-point windows: 4 waves x (1 x 5)

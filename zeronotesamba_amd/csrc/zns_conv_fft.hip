@@ -84,17 +84,22 @@ __global__ void __launch_bounds__(256) spec_fwd_kernel(const float* __restrict__
         const int qw = chunk * WINB + wbase;
         int R = qw / NB, bb = qw - R * NB;
         int left = CP - qw;                           // windows that exist from here on
+        // remap (the one-row layers, see geom()): the H "rows" of a channel are the samples of the batch, x is [H][C][T]:
+        // row R = c * H + h lives at tensor row h * C + c (tracked by increments: no division per window)
+        int rc = remap ? R / H : 0, rh = remap ? R - rc * H : 0;
 #pragma unroll
         for (int i = 0; i < WPW; ++i) {
 #pragma unroll
             for (int h = 0; h < K64; ++h) {           // a 128-sample window is two wave-instructions
                 const int smp = lane + 64 * h;
                 const int col = (bseg + bb) * V - off + smp;
-                // remap (the one-row layers, see geom()): the H "rows" of a channel are the samples of the batch, x is [H][C][T]
-                const size_t ro = remap ? ((size_t)(R % H) * C + R / H) * T : (size_t)R * T;
+                const size_t ro = remap ? ((size_t)rh * C + rc) * T : (size_t)R * T;
                 xw[i * K64 + h] = (i < left && bseg + bb < NBT && smp < valid && col >= 0 && col < T) ? xn[ro + col] : 0.f;
             }
-            if (++bb == NB) { bb = 0; ++R; }
+            if (++bb == NB) {
+                bb = 0; ++R;
+                if (++rh == H) { rh = 0; ++rc; }
+            }
         }
     }
 #pragma unroll
