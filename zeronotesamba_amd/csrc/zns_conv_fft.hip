@@ -1,4 +1,5 @@
-// Frequency-domain (overlap-save) form of the cv2..cv6 convolutions: same fp32 results, ~6x fewer MFMA FLOPs.
+// Frequency-domain (overlap-save) form of the cv2..cv8 convolutions: same fp32 results, ~6x fewer MFMA FLOPs (cv7 / cv8, the
+// one-row layers: ~10x; they run with the batch as the rows of one spectral sample per branch, see geom()).
 //
 // The kernels are wide along time (kw = 13..21 taps) and time is long (T = 313..626), so the time axis is cut
 // into 64-sample windows that overlap by kw-1 (V = 65-kw valid outputs per window).  A 64-point real DFT of each

@@ -1,4 +1,6 @@
-// fp32-MFMA implicit-GEMM convolutions for cv2..cv8 of _CNN (models.py:17-23, 41-70) on gfx950.
+// fp32-MFMA implicit-GEMM convolutions for cv2..cv8 of _CNN (models.py:17-23, 41-70) on gfx950: the DIRECT (time-domain) family.
+// ZNS_IMPL_AUTO runs cv2..cv8 in the frequency domain (zns_conv_fft.hip) wherever a row has at least 32 frames; these kernels
+// serve shorter rows, ZNS_IMPL_DIRECT and the parity tests that hold the two families together.
 //
 // Why fp32 MFMA: the parity bar is 1e-4 against the fp32 CPU reference with reductions up to
 // K = 26 880 (cv6); v_mfma_f32_32x32x2_f32 is bit-for-bit an fmaf chain, so the roofline for these
